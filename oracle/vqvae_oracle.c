@@ -1,0 +1,490 @@
+/*
+ * vqvae_oracle.c — CPU restatement of the VQVDB VQ-VAE leaf codec.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (vqvdb_amd/, include/) never links or calls it.
+ *
+ * What it restates (reference = /root/reference, ZephirFXEC/VQVDB @ 2025-09-05):
+ *   encode : VQVAE.encode            python/VQVAE_v2.py:350-369
+ *            EncoderFloat.forward    python/VQVAE_v2.py:231-250
+ *   decode : VQVAE.decode            python/VQVAE_v2.py:371-377
+ *            DecoderFloat.forward    python/VQVAE_v2.py:253-275
+ *   blocks : ResidualBlock :190-210, ChannelAttention :213-228, PixelShuffle3D :172-187,
+ *            nn.GroupNorm (biased variance, eps 1e-5), nn.Conv3d (cross-correlation, zero pad)
+ *   casts  : indices -> uint8 (TorchBackend.cpp:150), uint8 -> int (TorchBackend.cpp:179)
+ *
+ * Pinning: checked against tests/golden/golden_v1.npz (outputs of the imported reference
+ * model on synthetic weights/inputs; generator tests/golden/make_golden.py) by
+ * tests/test_oracle_golden.py — indices equal on every position whose recorded top-2
+ * relative gap is >= 1e-5, voxels/activations within 1e-5 relative.
+ *
+ * Arithmetic contract (what the HIP kernels reproduce BIT-EXACTLY on the encode path):
+ *   * all tensor arithmetic fp32, one rounding per operation, explicit fmaf() where a fused
+ *     multiply-add is meant; compiled with -ffp-contract=off.
+ *   * conv: acc = 0; for each VALID tap in ascending (kd,kh,kw) order, for input channels in
+ *     the layer's K-ORDER: acc = fmaf(w, x, acc); out = acc + bias.  Zero-padding taps are
+ *     skipped (identical to adding +0).  K-ORDER is the order an MFMA chain consumes K:
+ *       "P8"  (Cin multiple of 8): inside each aligned block of 8 channels 0,4,1,5,2,6,3,7
+ *       "P16" (Cin == 16)        : 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15
+ *       first conv (Cin == 1)    : K = (kd,kh) x {kw=0,1,2,pad}; invalid kw and the pad slot
+ *                                  contribute fmaf(w,0,acc) / fmaf(0,0,acc).
+ *       final conv (Cout == 1)   : natural ascending channel order.
+ *   * GroupNorm statistics: fp64 accumulators, positions ascending then channels ascending;
+ *     groups of 8 channels are the sum of two partials (low 4, high 4 channels);
+ *     mean = S/N, var = fma(-mean,mean,Q/N) clamped at 0, rstd = 1/sqrt(var+1e-5) in fp64,
+ *     both rounded to fp32.  Apply: a = rstd*gamma; b = fmaf(-mean,a,beta); y = fmaf(x,a,b).
+ *   * residual: out = skip + (0.1f * (acc + bias))      (two roundings)
+ *   * channel attention: mean = (sum over positions ascending) * (1/64); fc chains ascending;
+ *     sigmoid(x) = 1/(1+vq_expf(-x)) with the polynomial vq_expf below.
+ *   * VQ: dist = (zz + ee[k]) - 2*dot[k]  (VQVAE_v2.py:364-366), dot in "P8" order over the
+ *     128 latent channels, zz = partial(channels c with (c&4)==0) + partial((c&4)!=0), each
+ *     partial an fmaf chain over ascending c; ee[k] an fmaf chain over ascending c;
+ *     argmin = first minimum (torch.argmin).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LT 16 /* leaves processed together (SIMD lanes); per-leaf arithmetic is independent of LT */
+
+/* tensor order == vqvdb_amd/synth.py TENSORS */
+enum {
+    W_E_PRE0_W, W_E_PRE0_B, W_E_GN0_W, W_E_GN0_B,
+    W_E_R16_GN1_W, W_E_R16_GN1_B, W_E_R16_C1_W, W_E_R16_C1_B,
+    W_E_R16_GN2_W, W_E_R16_GN2_B, W_E_R16_C2_W, W_E_R16_C2_B,
+    W_E_DOWN_W, W_E_DOWN_B,
+    W_E_R32_GN1_W, W_E_R32_GN1_B, W_E_R32_C1_W, W_E_R32_C1_B,
+    W_E_R32_GN2_W, W_E_R32_GN2_B, W_E_R32_C2_W, W_E_R32_C2_B,
+    W_E_FC0, W_E_FC2, W_E_PROJ_W, W_E_PROJ_B,
+    W_D_STEM_W, W_D_STEM_B, W_D_GN0_W, W_D_GN0_B,
+    W_D_R64_GN1_W, W_D_R64_GN1_B, W_D_R64_C1_W, W_D_R64_C1_B,
+    W_D_R64_GN2_W, W_D_R64_GN2_B, W_D_R64_C2_W, W_D_R64_C2_B,
+    W_D_FC0, W_D_FC2, W_D_UP_W, W_D_UP_B, W_D_FINAL_W, W_D_FINAL_B,
+    W_CODEBOOK, W_COUNT
+};
+
+/* debug dump slots: each, if non-NULL, receives [B][C][NPOS] fp32 */
+enum { DBG_E_Y1, DBG_E_A1, DBG_E_Y4, DBG_E_A6, DBG_E_X7, DBG_E_Y9, DBG_E_X11, DBG_E_X12, DBG_E_Z,
+       DBG_D_YSTEM, DBG_D_D2, DBG_D_Y4, DBG_D_X6, DBG_D_X7, DBG_D_UP, DBG_D_PS, DBG_D_PRE, DBG_COUNT };
+
+int vqo_tensor_count(void) { return W_COUNT; }
+int vqo_debug_count(void) { return DBG_COUNT; }
+
+/* ---- exp: identical operation sequence on CPU and GPU (vqvdb_amd/csrc/vq_math.h) ---- */
+static inline float vq_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);          /* ln2 hi (exact in 12 bits) */
+    r = fmaf(n, -1.42860682030941723212e-6f, r);        /* ln2 lo */
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float e = fmaf(p, r2, r) + 1.0f;
+    union { float f; int32_t i; } u;
+    u.f = e;
+    u.i += ((int32_t)n) << 23;
+    return u.f;
+}
+float vqo_expf(float x) { return vq_expf(x); }
+
+static inline float vq_sigmoid(float x) { return 1.0f / (1.0f + vq_expf(-x)); }
+
+/* ---- K orders ---- */
+static void korder_p8(int cin, int* ord)
+{
+    static const int p[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    for (int c = 0; c < cin; ++c) ord[c] = (c & ~7) + p[c & 7];
+}
+static void korder_p16(int* ord)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < 4; ++q) ord[i * 4 + q] = 4 * q + i;
+}
+static void korder_nat(int cin, int* ord) { for (int c = 0; c < cin; ++c) ord[c] = c; }
+
+/* ---- conv3d, activations [C][S^3][LT] ---- */
+static void conv3d(const float* in, float* out, const float* W, const float* bias,
+                   int CIN, int COUT, int SI, int SO, int K, int stride, int pad, const int* kord)
+{
+    const int NPI = SI * SI * SI, NPO = SO * SO * SO, K3 = K * K * K;
+    for (int co = 0; co < COUT; ++co) {
+        const float* Wc = W + (size_t)co * CIN * K3;
+        for (int od = 0; od < SO; ++od)
+        for (int oh = 0; oh < SO; ++oh)
+        for (int ow = 0; ow < SO; ++ow) {
+            float acc[LT];
+            for (int l = 0; l < LT; ++l) acc[l] = 0.0f;
+            for (int kd = 0; kd < K; ++kd) {
+                const int id = od * stride - pad + kd;
+                if (id < 0 || id >= SI) continue;
+                for (int kh = 0; kh < K; ++kh) {
+                    const int ih = oh * stride - pad + kh;
+                    if (ih < 0 || ih >= SI) continue;
+                    for (int kw = 0; kw < K; ++kw) {
+                        const int iw = ow * stride - pad + kw;
+                        if (iw < 0 || iw >= SI) continue;
+                        const int ip = (id * SI + ih) * SI + iw;
+                        const int tap = (kd * K + kh) * K + kw;
+                        for (int cc = 0; cc < CIN; ++cc) {
+                            const int ci = kord[cc];
+                            const float w = Wc[(size_t)ci * K3 + tap];
+                            const float* x = in + ((size_t)ci * NPI + ip) * LT;
+                            for (int l = 0; l < LT; ++l) acc[l] = fmaf(w, x[l], acc[l]);
+                        }
+                    }
+                }
+            }
+            float* o = out + ((size_t)co * NPO + (od * SO + oh) * SO + ow) * LT;
+            const float b = bias[co];
+            for (int l = 0; l < LT; ++l) o[l] = acc[l] + b;
+        }
+    }
+}
+
+/* first conv (Cin = 1, k3 p1) in its MFMA-shaped order: (kd,kh) valid, then kw = 0,1,2,pad */
+static void conv_first(const float* in /*[512][LT]*/, float* out /*[16][512][LT]*/, const float* W, const float* bias)
+{
+    for (int co = 0; co < 16; ++co)
+    for (int od = 0; od < 8; ++od)
+    for (int oh = 0; oh < 8; ++oh)
+    for (int ow = 0; ow < 8; ++ow) {
+        float acc[LT];
+        for (int l = 0; l < LT; ++l) acc[l] = 0.0f;
+        for (int kd = 0; kd < 3; ++kd) {
+            const int id = od - 1 + kd;
+            if (id < 0 || id >= 8) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh - 1 + kh;
+                if (ih < 0 || ih >= 8) continue;
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int iw = ow - 1 + kw;
+                    const int ok = (kw < 3) && iw >= 0 && iw < 8;
+                    const float w = (kw < 3) ? W[co * 27 + (kd * 3 + kh) * 3 + kw] : 0.0f;
+                    const float* x = in + (size_t)((id * 8 + ih) * 8 + (ok ? iw : 0)) * LT;
+                    for (int l = 0; l < LT; ++l) acc[l] = fmaf(w, ok ? x[l] : 0.0f, acc[l]);
+                }
+            }
+        }
+        float* o = out + ((size_t)co * 512 + (od * 8 + oh) * 8 + ow) * LT;
+        for (int l = 0; l < LT; ++l) o[l] = acc[l] + bias[co];
+    }
+}
+
+/* ---- GroupNorm ---- */
+static void gn_stats(const float* x, int C, int G, int NP, float* mean /*[G][LT]*/, float* rstd)
+{
+    const int cpg = C / G;
+    const int nparts = (cpg == 8) ? 2 : 1, cpp = cpg / nparts;
+    const double invN = 1.0 / (double)(cpg * NP);
+    for (int g = 0; g < G; ++g) {
+        double S[LT], Q[LT];
+        for (int l = 0; l < LT; ++l) S[l] = Q[l] = 0.0;
+        for (int part = 0; part < nparts; ++part) {
+            double s[LT], q[LT];
+            for (int l = 0; l < LT; ++l) s[l] = q[l] = 0.0;
+            for (int p = 0; p < NP; ++p)
+                for (int cc = 0; cc < cpp; ++cc) {
+                    const float* v = x + ((size_t)(g * cpg + part * cpp + cc) * NP + p) * LT;
+                    for (int l = 0; l < LT; ++l) {
+                        const double d = (double)v[l];
+                        s[l] += d;
+                        q[l] = fma(d, d, q[l]);
+                    }
+                }
+            if (part == 0) for (int l = 0; l < LT; ++l) { S[l] = s[l]; Q[l] = q[l]; }
+            else for (int l = 0; l < LT; ++l) { S[l] = S[l] + s[l]; Q[l] = Q[l] + q[l]; }
+        }
+        for (int l = 0; l < LT; ++l) {
+            const double m = S[l] * invN, ex2 = Q[l] * invN;
+            double var = fma(-m, m, ex2);
+            if (var < 0.0) var = 0.0;
+            mean[g * LT + l] = (float)m;
+            rstd[g * LT + l] = (float)(1.0 / sqrt(var + 1e-5));
+        }
+    }
+}
+
+static void gn_relu(const float* x, float* y, int C, int G, int NP, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta)
+{
+    const int cpg = C / G;
+    for (int c = 0; c < C; ++c) {
+        const int g = c / cpg;
+        float a[LT], b[LT];
+        for (int l = 0; l < LT; ++l) {
+            a[l] = rstd[g * LT + l] * gamma[c];
+            b[l] = fmaf(-mean[g * LT + l], a[l], beta[c]);
+        }
+        for (int p = 0; p < NP; ++p) {
+            const float* v = x + ((size_t)c * NP + p) * LT;
+            float* o = y + ((size_t)c * NP + p) * LT;
+            for (int l = 0; l < LT; ++l) {
+                const float t = fmaf(v[l], a[l], b[l]);
+                o[l] = t > 0.0f ? t : 0.0f;
+            }
+        }
+    }
+}
+
+/* ResidualBlock (VQVAE_v2.py:190-210); x,out [C][NP][LT]; optional dump of conv1 output */
+static void res_block(const float* x, float* out, float* t0, float* t1, int C, int S, const float* const* W, int base,
+                      const int* kord, float* y_mid_dump)
+{
+    const int NP = S * S * S;
+    float mean[8 * LT], rstd[8 * LT];
+    gn_stats(x, C, 8, NP, mean, rstd);
+    gn_relu(x, t0, C, 8, NP, mean, rstd, W[base + 0], W[base + 1]);
+    conv3d(t0, t1, W[base + 2], W[base + 3], C, C, S, S, 3, 1, 1, kord);
+    if (y_mid_dump) memcpy(y_mid_dump, t1, sizeof(float) * C * NP * LT);
+    gn_stats(t1, C, 8, NP, mean, rstd);
+    gn_relu(t1, t0, C, 8, NP, mean, rstd, W[base + 4], W[base + 5]);
+    /* conv2 without bias add, then out = x + 0.1*(acc + bias) */
+    static const float zero_bias[256] = {0};
+    conv3d(t0, t1, W[base + 6], zero_bias, C, C, S, S, 3, 1, 1, kord);
+    const float* bias = W[base + 7];
+    for (int c = 0; c < C; ++c)
+        for (int p = 0; p < NP; ++p)
+            for (int l = 0; l < LT; ++l) {
+                const size_t i = ((size_t)c * NP + p) * LT + l;
+                const float t = t1[i] + bias[c]; /* t1 = acc (+0 bias) */
+                const float u = 0.1f * t;
+                out[i] = x[i] + u;
+            }
+}
+
+/* ChannelAttention (VQVAE_v2.py:213-228), 64 positions */
+static void channel_attention(const float* x, float* out, int C, const float* fc0 /*[C/4][C]*/, const float* fc2 /*[C][C/4]*/)
+{
+    const int R = C / 4, NP = 64;
+    float m[64][LT], h[16][LT];
+    for (int c = 0; c < C; ++c) {
+        float s[LT];
+        for (int l = 0; l < LT; ++l) s[l] = 0.0f;
+        for (int p = 0; p < NP; ++p)
+            for (int l = 0; l < LT; ++l) s[l] = s[l] + x[((size_t)c * NP + p) * LT + l];
+        for (int l = 0; l < LT; ++l) m[c][l] = s[l] * (1.0f / 64.0f);
+    }
+    for (int j = 0; j < R; ++j)
+        for (int l = 0; l < LT; ++l) {
+            float a = 0.0f;
+            for (int c = 0; c < C; ++c) a = fmaf(fc0[j * C + c], m[c][l], a);
+            h[j][l] = a > 0.0f ? a : 0.0f;
+        }
+    for (int c = 0; c < C; ++c)
+        for (int l = 0; l < LT; ++l) {
+            float a = 0.0f;
+            for (int j = 0; j < R; ++j) a = fmaf(fc2[c * R + j], h[j][l], a);
+            const float s = vq_sigmoid(a);
+            for (int p = 0; p < NP; ++p) {
+                const size_t i = ((size_t)c * NP + p) * LT + l;
+                out[i] = x[i] * s;
+            }
+        }
+}
+
+static void dump(float* dst, const float* src, int C, int NP, int64_t leaf0, int nl)
+{
+    if (!dst) return;
+    for (int l = 0; l < nl; ++l)
+        for (int c = 0; c < C; ++c)
+            for (int p = 0; p < NP; ++p)
+                dst[((size_t)(leaf0 + l) * C + c) * NP + p] = src[((size_t)c * NP + p) * LT + l];
+}
+
+typedef struct {
+    float *a, *b, *c, *d; /* scratch, each 256*64*LT = 16*512*LT*2 floats */
+} scratch_t;
+
+static void encode_tile(const float* const* W, const float* leaves, int64_t leaf0, int nl, uint8_t* idx,
+                        float* const* dbg, scratch_t* s, const float* ee)
+{
+    int p8_16[16], p16[16], p8_32[32], p8_128[128];
+    korder_p8(16, p8_16); korder_p16(p16); korder_p8(32, p8_32); korder_p8(128, p8_128);
+    float* x = s->a;   /* [512][LT] */
+    for (int p = 0; p < 512; ++p)
+        for (int l = 0; l < LT; ++l) x[p * LT + l] = (l < nl) ? leaves[(size_t)(leaf0 + l) * 512 + p] : 0.0f;
+    float* y1 = s->b;
+    conv_first(x, y1, W[W_E_PRE0_W], W[W_E_PRE0_B]);
+    if (dbg) dump(dbg[DBG_E_Y1], y1, 16, 512, leaf0, nl);
+    float mean[8 * LT], rstd[8 * LT];
+    gn_stats(y1, 16, 4, 512, mean, rstd);
+    float* a1 = s->c;
+    gn_relu(y1, a1, 16, 4, 512, mean, rstd, W[W_E_GN0_W], W[W_E_GN0_B]);
+    if (dbg) dump(dbg[DBG_E_A1], a1, 16, 512, leaf0, nl);
+    float* a6 = s->d;
+    float* y4d = NULL;
+    float* y4tmp = NULL;
+    if (dbg && dbg[DBG_E_Y4]) { y4tmp = (float*)malloc(sizeof(float) * 16 * 512 * LT); y4d = y4tmp; }
+    res_block(a1, a6, s->a, s->b, 16, 8, W, W_E_R16_GN1_W, p16, y4d);
+    if (y4tmp) { dump(dbg[DBG_E_Y4], y4tmp, 16, 512, leaf0, nl); free(y4tmp); }
+    if (dbg) dump(dbg[DBG_E_A6], a6, 16, 512, leaf0, nl);
+    float* x7 = s->c;
+    conv3d(a6, x7, W[W_E_DOWN_W], W[W_E_DOWN_B], 16, 32, 8, 4, 4, 2, 1, p8_16);
+    if (dbg) dump(dbg[DBG_E_X7], x7, 32, 64, leaf0, nl);
+    float* x11 = s->d;
+    float* y9tmp = NULL;
+    if (dbg && dbg[DBG_E_Y9]) y9tmp = (float*)malloc(sizeof(float) * 32 * 64 * LT);
+    res_block(x7, x11, s->a, s->b, 32, 4, W, W_E_R32_GN1_W, p8_32, y9tmp);
+    if (y9tmp) { dump(dbg[DBG_E_Y9], y9tmp, 32, 64, leaf0, nl); free(y9tmp); }
+    if (dbg) dump(dbg[DBG_E_X11], x11, 32, 64, leaf0, nl);
+    float* x12 = s->a;
+    channel_attention(x11, x12, 32, W[W_E_FC0], W[W_E_FC2]);
+    if (dbg) dump(dbg[DBG_E_X12], x12, 32, 64, leaf0, nl);
+    float* z = s->b; /* [128][64][LT] */
+    conv3d(x12, z, W[W_E_PROJ_W], W[W_E_PROJ_B], 32, 128, 4, 4, 1, 1, 0, p8_32);
+    if (dbg) dump(dbg[DBG_E_Z], z, 128, 64, leaf0, nl);
+    /* nearest code (VQVAE_v2.py:358-367) */
+    const float* E = W[W_CODEBOOK];
+    for (int p = 0; p < 64; ++p) {
+        float zz0[LT], zz1[LT], zz[LT], best[LT];
+        int bi[LT];
+        for (int l = 0; l < LT; ++l) { zz0[l] = zz1[l] = 0.0f; }
+        for (int c = 0; c < 128; ++c) {
+            const float* v = z + ((size_t)c * 64 + p) * LT;
+            if ((c & 4) == 0) for (int l = 0; l < LT; ++l) zz0[l] = fmaf(v[l], v[l], zz0[l]);
+            else for (int l = 0; l < LT; ++l) zz1[l] = fmaf(v[l], v[l], zz1[l]);
+        }
+        for (int l = 0; l < LT; ++l) { zz[l] = zz0[l] + zz1[l]; best[l] = INFINITY; bi[l] = 0; }
+        for (int k = 0; k < 256; ++k) {
+            float dot[LT];
+            for (int l = 0; l < LT; ++l) dot[l] = 0.0f;
+            for (int cc = 0; cc < 128; ++cc) {
+                const int c = p8_128[cc];
+                const float e = E[k * 128 + c];
+                const float* v = z + ((size_t)c * 64 + p) * LT;
+                for (int l = 0; l < LT; ++l) dot[l] = fmaf(e, v[l], dot[l]);
+            }
+            for (int l = 0; l < LT; ++l) {
+                const float d = (zz[l] + ee[k]) - 2.0f * dot[l];
+                if (d < best[l]) { best[l] = d; bi[l] = k; }
+            }
+        }
+        for (int l = 0; l < nl; ++l) idx[(size_t)(leaf0 + l) * 64 + p] = (uint8_t)bi[l];
+    }
+}
+
+static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0, int nl, float* out,
+                        float* const* dbg, scratch_t* s)
+{
+    int p8_64[64], p8_128[128], nat32[32];
+    korder_p8(64, p8_64); korder_p8(128, p8_128); korder_nat(32, nat32);
+    const float* E = W[W_CODEBOOK];
+    float* q = s->a; /* [128][64][LT] */
+    for (int c = 0; c < 128; ++c)
+        for (int p = 0; p < 64; ++p)
+            for (int l = 0; l < LT; ++l) {
+                const int k = (l < nl) ? idx[(size_t)(leaf0 + l) * 64 + p] : 0;
+                q[((size_t)c * 64 + p) * LT + l] = E[k * 128 + c];
+            }
+    float* y = s->b;
+    conv3d(q, y, W[W_D_STEM_W], W[W_D_STEM_B], 128, 64, 4, 4, 3, 1, 1, p8_128);
+    if (dbg) dump(dbg[DBG_D_YSTEM], y, 64, 64, leaf0, nl);
+    float mean[8 * LT], rstd[8 * LT];
+    gn_stats(y, 64, 8, 64, mean, rstd);
+    float* d2 = s->c;
+    gn_relu(y, d2, 64, 8, 64, mean, rstd, W[W_D_GN0_W], W[W_D_GN0_B]);
+    if (dbg) dump(dbg[DBG_D_D2], d2, 64, 64, leaf0, nl);
+    float* x6 = s->d;
+    float* y4tmp = NULL;
+    if (dbg && dbg[DBG_D_Y4]) y4tmp = (float*)malloc(sizeof(float) * 64 * 64 * LT);
+    res_block(d2, x6, s->a, s->b, 64, 4, W, W_D_R64_GN1_W, p8_64, y4tmp);
+    if (y4tmp) { dump(dbg[DBG_D_Y4], y4tmp, 64, 64, leaf0, nl); free(y4tmp); }
+    if (dbg) dump(dbg[DBG_D_X6], x6, 64, 64, leaf0, nl);
+    float* x7 = s->a;
+    channel_attention(x6, x7, 64, W[W_D_FC0], W[W_D_FC2]);
+    if (dbg) dump(dbg[DBG_D_X7], x7, 64, 64, leaf0, nl);
+    float* up = s->b; /* [256][64][LT] */
+    conv3d(x7, up, W[W_D_UP_W], W[W_D_UP_B], 64, 256, 4, 4, 3, 1, 1, p8_64);
+    if (dbg) dump(dbg[DBG_D_UP], up, 256, 64, leaf0, nl);
+    /* PixelShuffle3D(2) (VQVAE_v2.py:172-187): out[oc][2d+i][2h+j][2w+k] = in[oc*8+i*4+j*2+k][d][h][w] */
+    float* ps = s->c; /* [32][512][LT] */
+    for (int oc = 0; oc < 32; ++oc)
+        for (int d = 0; d < 4; ++d) for (int h = 0; h < 4; ++h) for (int w = 0; w < 4; ++w)
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+                const int ci = oc * 8 + i * 4 + j * 2 + k;
+                const int po = ((2 * d + i) * 8 + (2 * h + j)) * 8 + (2 * w + k);
+                memcpy(ps + ((size_t)oc * 512 + po) * LT, up + ((size_t)ci * 64 + (d * 4 + h) * 4 + w) * LT, sizeof(float) * LT);
+            }
+    if (dbg) dump(dbg[DBG_D_PS], ps, 32, 512, leaf0, nl);
+    float* pre = s->d; /* [1][512][LT] */
+    conv3d(ps, pre, W[W_D_FINAL_W], W[W_D_FINAL_B], 32, 1, 8, 8, 3, 1, 1, nat32);
+    if (dbg) dump(dbg[DBG_D_PRE], pre, 1, 512, leaf0, nl);
+    for (int p = 0; p < 512; ++p)
+        for (int l = 0; l < nl; ++l) out[(size_t)(leaf0 + l) * 512 + p] = vq_sigmoid(pre[p * LT + l]);
+}
+
+static int scratch_init(scratch_t* s)
+{
+    const size_t n = (size_t)256 * 64 * LT;
+    s->a = (float*)malloc(n * sizeof(float)); s->b = (float*)malloc(n * sizeof(float));
+    s->c = (float*)malloc(n * sizeof(float)); s->d = (float*)malloc(n * sizeof(float));
+    return (s->a && s->b && s->c && s->d) ? 0 : -1;
+}
+static void scratch_free(scratch_t* s) { free(s->a); free(s->b); free(s->c); free(s->d); }
+
+/* ee[k] = sum_c E[k][c]^2, fmaf chain ascending c (host-side precompute in the product too) */
+void vqo_code_norms(const float* E, float* ee)
+{
+    for (int k = 0; k < 256; ++k) {
+        float s = 0.0f;
+        for (int c = 0; c < 128; ++c) s = fmaf(E[k * 128 + c], E[k * 128 + c], s);
+        ee[k] = s;
+    }
+}
+
+int vqo_encode(const float* const* W, const float* leaves, int64_t B, uint8_t* idx, float* const* dbg, int nthreads)
+{
+    if (B <= 0) return 0;
+    float ee[256];
+    vqo_code_norms(W[W_CODEBOOK], ee);
+    const int64_t ntiles = (B + LT - 1) / LT;
+    int err = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        scratch_t s;
+        if (scratch_init(&s) != 0) {
+#pragma omp atomic write
+            err = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t t = 0; t < ntiles; ++t) {
+                const int nl = (int)((B - t * LT) < LT ? (B - t * LT) : LT);
+                encode_tile(W, leaves, t * LT, nl, idx, dbg, &s, ee);
+            }
+        }
+        scratch_free(&s);
+    }
+    return err;
+}
+
+int vqo_decode(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads)
+{
+    if (B <= 0) return 0;
+    const int64_t ntiles = (B + LT - 1) / LT;
+    int err = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        scratch_t s;
+        if (scratch_init(&s) != 0) {
+#pragma omp atomic write
+            err = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t t = 0; t < ntiles; ++t) {
+                const int nl = (int)((B - t * LT) < LT ? (B - t * LT) : LT);
+                decode_tile(W, idx, t * LT, nl, out, dbg, &s);
+            }
+        }
+        scratch_free(&s);
+    }
+    return err;
+}
