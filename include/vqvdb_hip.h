@@ -1,0 +1,113 @@
+/*
+ * vqvdb_hip.h — C ABI of libvqvdb_hip.so, the MI355X (gfx950) backend for VQVDB's
+ * VQ-VAE leaf codec.  No C++ / torch / ONNX types cross this boundary.
+ *
+ * This is what a `HipBackend final : IVQVAECodec` (sibling of the reference's
+ * src/backends/torch/TorchBackend.{hpp,cpp} and src/backends/onnx/OnnxBackend_Cuda.cpp)
+ * binds; the adapter lives in include/vqvdb_hip_backend.hpp, the factory hook and the
+ * maintainer-side diff are in INTEGRATION.md.
+ *
+ * Tensor contracts (reference: src/core/IVQVAECodec.hpp:114-135, layout fixed by the
+ * orchestrator's packing loops src/orchestrator/VQVAECodec.cpp:36-59,182-192):
+ *   leaves  : float32 [n_leaves][512]  = TensorView shape [B,1,8,8,8]; leaf i occupies floats
+ *             [i*512,(i+1)*512) in OpenVDB leaf-buffer order (offset = d*64 + h*8 + w).
+ *   indices : uint8   [n_leaves][64]   = Tensor shape [B,4,4,4]; position = d*16 + h*4 + w.
+ *
+ * Every function returns VQHIP_OK (0) or a negative status; the message is available from
+ * vqhip_last_error().  Nothing throws, nothing aborts.  A codec handle owns its device
+ * buffers and streams; distinct handles may be used from distinct threads concurrently,
+ * one handle is used by one thread at a time (the reference orchestrator calls
+ * encode/decode serially: VQVAECodec.cpp:108-127,166-196).
+ */
+#ifndef VQVDB_HIP_H
+#define VQVDB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQHIP_OK 0
+#define VQHIP_ERR_INVALID (-1)   /* bad argument / shape / dtype                      */
+#define VQHIP_ERR_MODEL (-2)     /* weight pack missing, malformed or wrong shapes    */
+#define VQHIP_ERR_DEVICE (-3)    /* HIP runtime error (message carries hipGetErrorString) */
+#define VQHIP_ERR_NOMEM (-4)
+
+#define VQHIP_LEAF_VOXELS 512
+#define VQHIP_LATENT_VOXELS 64
+
+typedef struct vqhip_codec vqhip_codec;
+
+/* Replaces: TorchBackend::TorchBackend(const CodecConfig&) (TorchBackend.cpp:84-95) and
+ * load_model() (TorchBackend.cpp:38-60).  Model source is a VQWPACK1 weight pack
+ * (vqvdb_amd/weightpack.py): `pack_path` (CodecConfig.source = filesystem::path) or, when
+ * pack_path is NULL, `pack_bytes`/`pack_size` (CodecConfig.source = EmbeddedModel).
+ * device_id: HIP device ordinal.  On failure *out = NULL and the message is retrievable
+ * with vqhip_last_error(NULL). */
+int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size, int device_id, vqhip_codec** out);
+
+void vqhip_destroy(vqhip_codec* codec);
+
+/* Message of the last failure on this handle (codec == NULL: last failure of
+ * vqhip_create on the calling thread).  Never NULL. */
+const char* vqhip_last_error(const vqhip_codec* codec);
+
+/* Replaces: getLatentShape() (IVQVAECodec.hpp:135) and the zero-leaf probe
+ * initialize_latent_shape() (TorchBackend.cpp:97-119).  The shape is derived from the
+ * loaded weights; out = {4,4,4}. */
+int vqhip_latent_shape(const vqhip_codec* codec, int64_t out[3]);
+
+/* Replaces: TorchBackend::encode (TorchBackend.cpp:133-164) / OnnxCudaBackend::encode_impl
+ * (OnnxBackend_Cuda.cpp:83-123).  Host pointers, caller-owned; n_leaves >= 1. */
+int vqhip_encode(vqhip_codec* codec, const float* leaves, int64_t n_leaves, uint8_t* indices);
+
+/* Replaces: TorchBackend::decode (TorchBackend.cpp:166-194) / OnnxCudaBackend::decode_impl
+ * (OnnxBackend_Cuda.cpp:125-165). */
+int vqhip_decode(vqhip_codec* codec, const uint8_t* indices, int64_t n_leaves, float* leaves);
+
+/* Device-resident variants (no reference counterpart: the reference backends always stage
+ * through host memory).  Pointers are device pointers on the codec's device; work is
+ * enqueued on `hip_stream` (a hipStream_t, NULL = the codec's own stream) and is NOT
+ * synchronised on return. */
+int vqhip_encode_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, uint8_t* indices_dev, void* hip_stream);
+int vqhip_decode_device(vqhip_codec* codec, const uint8_t* indices_dev, int64_t n_leaves, float* leaves_dev, void* hip_stream);
+
+/* Leaves processed per internal pass (default 65536).  Bounds the device workspace
+ * (about 0.26 MB per leaf). */
+int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
+
+/* ---- measurement hooks (bench.py / tests) ---- */
+
+/* Per-kernel timing with HIP events on the launch stream.  While enabled, every kernel
+ * launch is bracketed by events; vqhip_profile_read() synchronises and returns, for up to
+ * `cap` kernels, name / launch count / total milliseconds, and resets the counters. */
+typedef struct vqhip_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double flops_per_leaf;     /* nominal dense FLOPs this kernel performs per leaf (0 for data-movement kernels) */
+    double eff_flops_per_leaf; /* same, zero-padding taps excluded */
+    int64_t leaves;            /* leaves processed over the counted launches */
+} vqhip_kernel_stat;
+int vqhip_profile_enable(vqhip_codec* codec, int enable);
+int vqhip_profile_read(vqhip_codec* codec, vqhip_kernel_stat* stats, int cap, int* count);
+
+/* Test hooks.  vqhip_debug_enable(1) makes encode also keep the 128-channel latent (it is
+ * otherwise never written to memory).  vqhip_debug_fetch copies an intermediate activation
+ * of the LAST encode/decode chunk to host as float32 [n_leaves][C][positions] (NCDHW
+ * flattened).  Names: e_y1 e_a1 e_y4 e_a6 e_x7 e_y9 e_x11 e_z d_q d_ystem d_d2 d_y4 d_x6 d_ps. */
+int vqhip_debug_enable(vqhip_codec* codec, int enable);
+int vqhip_debug_fetch(vqhip_codec* codec, const char* name, int64_t n_leaves, float* out);
+
+/* Hardware assumption check: runs fp32 MFMA chains against per-lane fmaf chains in K order
+ * on the device; mismatches[0] = differing elements for 32x32x2, mismatches[1] for 16x16x4. */
+int vqhip_selftest_mfma(vqhip_codec* codec, int64_t mismatches[2]);
+
+const char* vqhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQVDB_HIP_H */

@@ -1,0 +1,46 @@
+"""Builds libvqvdb_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m vqvdb_amd.build [--report]
+
+-ffp-contract=off: the kernels' arithmetic contract uses explicit fmaf only.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "vq_runtime.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "vq_kernels.h"), os.path.join(HERE, "csrc", "vq_device.h"),
+        os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip.h")]
+LIB = os.path.join(HERE, "libvqvdb_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def build(force: bool = False, report: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    stale = force or report or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+    if stale:
+        cmd = [hipcc, *FLAGS, SRC, "-o", LIB]
+        if report:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise RuntimeError("hipcc failed building libvqvdb_hip.so")
+        if report:
+            name = None
+            for line in r.stderr.splitlines():
+                if "Function Name:" in line:
+                    name = line.split("Function Name:")[1].split("[")[0].strip()
+                for key in ("VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill", "SGPRs Spill", "LDS Size"):
+                    if key in line and "remark" in line:
+                        print(f"{name:110s} {line.split('remark:')[1].split('[-R')[0].strip()}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, report="--report" in sys.argv)
+    print(LIB)

@@ -1,0 +1,262 @@
+"""Host-side mirror of the reference's codec interface over the C ABI of libvqvdb_hip.so.
+
+Mirrors src/core/IVQVAECodec.hpp (``BackendType``, ``DataType``, ``TensorView``, ``Tensor``,
+``CodecConfig``, ``IVQVAECodec.create/encode/decode/getLatentShape``) with the same names,
+argument meaning and error behaviour, so the parity tests read like the reference's call
+sites (src/orchestrator/VQVAECodec.cpp:108-127,166-196).  The C++ adapter a maintainer would
+compile into the reference tree is include/vqvdb_hip_backend.hpp; this module is the same
+thing for Python callers, tests and bench.py.
+
+There is NO CPU fallback: if the shared library or a gfx950 device is missing, ``create``
+reports the failure and returns ``None`` exactly like the reference factory
+(src/core/IVQVAECodec.cpp:106-109), and ``HipCodec`` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+import sys
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqvdb_hip.so")
+
+LEAF_VOXELS = 512
+LATENT_VOXELS = 64
+
+
+class BackendType(enum.Enum):   # IVQVAECodec.hpp:21, HIP appended (existing values unchanged)
+    LibTorch = 0
+    ONNX = 1
+    HIP = 2
+
+
+class DataType(enum.Enum):      # IVQVAECodec.hpp:38-41
+    FLOAT32 = 0
+    UINT8 = 1
+
+
+class EmbeddedModel:            # IVQVAECodec.hpp:27
+    pass
+
+
+@dataclass
+class TensorView:               # IVQVAECodec.hpp:49-53 — non-owning view of host data
+    data: np.ndarray
+    shape: Sequence[int]
+    dtype: DataType
+
+
+@dataclass
+class Tensor:                   # IVQVAECodec.hpp:61-80 — owning result
+    buffer: np.ndarray          # flat uint8 bytes
+    shape: list
+    dtype: DataType
+
+    def getData(self) -> np.ndarray:
+        t = np.float32 if self.dtype == DataType.FLOAT32 else np.uint8
+        return self.buffer.view(t).reshape(self.shape)
+
+
+@dataclass
+class CodecConfig:              # IVQVAECodec.hpp:85-89
+    class Device(enum.Enum):
+        CPU = 0
+        CUDA = 1                # read as "GPU": the HIP backend only accepts this value
+
+    device: "CodecConfig.Device" = None
+    source: Union[EmbeddedModel, str, os.PathLike, bytes] = field(default_factory=EmbeddedModel)
+    device_id: int = 0          # extension: HIP device ordinal (reference hard-codes 0, OnnxBackend_Cuda.cpp:21)
+
+    def __post_init__(self):
+        if self.device is None:
+            self.device = CodecConfig.Device.CPU
+
+
+class _KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_int64), ("total_ms", ctypes.c_double),
+                ("flops_per_leaf", ctypes.c_double), ("eff_flops_per_leaf", ctypes.c_double), ("leaves", ctypes.c_int64)]
+
+
+# every symbol include/vqvdb_hip.h declares
+ABI_SYMBOLS = [
+    "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_latent_shape", "vqhip_encode", "vqhip_decode",
+    "vqhip_encode_device", "vqhip_decode_device", "vqhip_set_chunk_leaves", "vqhip_profile_enable",
+    "vqhip_profile_read", "vqhip_debug_enable", "vqhip_debug_fetch", "vqhip_selftest_mfma", "vqhip_version",
+]
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libvqvdb_hip.so (built in-tree by ``python -m vqvdb_amd.build``) and type its ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m vqvdb_amd.build` (no CPU fallback exists)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.vqhip_create.argtypes = [ctypes.c_char_p, vp, ctypes.c_size_t, ci, ctypes.POINTER(vp)]
+    lib.vqhip_destroy.argtypes = [vp]
+    lib.vqhip_destroy.restype = None
+    lib.vqhip_last_error.argtypes = [vp]
+    lib.vqhip_last_error.restype = ctypes.c_char_p
+    lib.vqhip_latent_shape.argtypes = [vp, ctypes.POINTER(i64)]
+    lib.vqhip_encode.argtypes = [vp, vp, i64, vp]
+    lib.vqhip_decode.argtypes = [vp, vp, i64, vp]
+    lib.vqhip_encode_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.vqhip_decode_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.vqhip_set_chunk_leaves.argtypes = [vp, i64]
+    lib.vqhip_profile_enable.argtypes = [vp, ci]
+    lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
+    lib.vqhip_debug_enable.argtypes = [vp, ci]
+    lib.vqhip_debug_fetch.argtypes = [vp, ctypes.c_char_p, i64, vp]
+    lib.vqhip_selftest_mfma.argtypes = [vp, ctypes.POINTER(i64)]
+    lib.vqhip_version.restype = ctypes.c_char_p
+    for name in ABI_SYMBOLS:
+        if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version"):
+            getattr(lib, name).restype = ci
+    _lib = lib
+    return lib
+
+
+class HipCodec:
+    """Thin owner of a ``vqhip_codec*`` — the C ABI one-to-one, numpy/raw pointers in and out."""
+
+    def __init__(self, pack: Union[str, os.PathLike, bytes], device_id: int = 0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        if isinstance(pack, (bytes, bytearray, memoryview)):
+            self._pack = bytes(pack)
+            rc = self._lib.vqhip_create(None, self._pack, len(self._pack), device_id, ctypes.byref(self._h))
+        else:
+            rc = self._lib.vqhip_create(os.fspath(pack).encode(), None, 0, device_id, ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(self._lib.vqhip_last_error(None).decode())
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(self._lib.vqhip_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.vqhip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def latent_shape(self) -> list:
+        out = (ctypes.c_int64 * 3)()
+        self._check(self._lib.vqhip_latent_shape(self._h, out))
+        return list(out)
+
+    def encode(self, leaves: np.ndarray) -> np.ndarray:
+        leaves = np.ascontiguousarray(leaves, dtype=np.float32).reshape(-1, LEAF_VOXELS)
+        idx = np.empty((leaves.shape[0], LATENT_VOXELS), dtype=np.uint8)
+        self._check(self._lib.vqhip_encode(self._h, leaves.ctypes.data, leaves.shape[0], idx.ctypes.data))
+        return idx
+
+    def decode(self, indices: np.ndarray) -> np.ndarray:
+        indices = np.ascontiguousarray(indices, dtype=np.uint8).reshape(-1, LATENT_VOXELS)
+        out = np.empty((indices.shape[0], LEAF_VOXELS), dtype=np.float32)
+        self._check(self._lib.vqhip_decode(self._h, indices.ctypes.data, indices.shape[0], out.ctypes.data))
+        return out
+
+    def encode_device(self, leaves_ptr: int, n: int, idx_ptr: int, stream: int = 0):
+        self._check(self._lib.vqhip_encode_device(self._h, leaves_ptr, n, idx_ptr, stream or None))
+
+    def decode_device(self, idx_ptr: int, n: int, leaves_ptr: int, stream: int = 0):
+        self._check(self._lib.vqhip_decode_device(self._h, idx_ptr, n, leaves_ptr, stream or None))
+
+    def set_chunk_leaves(self, n: int):
+        self._check(self._lib.vqhip_set_chunk_leaves(self._h, n))
+
+    def profile_enable(self, on: bool):
+        self._check(self._lib.vqhip_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> list:
+        stats = (_KernelStat * 64)()
+        cnt = ctypes.c_int()
+        self._check(self._lib.vqhip_profile_read(self._h, stats, 64, ctypes.byref(cnt)))
+        return [dict(name=s.name.decode(), launches=s.launches, total_ms=s.total_ms, flops_per_leaf=s.flops_per_leaf,
+                     eff_flops_per_leaf=s.eff_flops_per_leaf, leaves=s.leaves) for s in stats[:cnt.value]]
+
+    def debug_enable(self, on: bool):
+        self._check(self._lib.vqhip_debug_enable(self._h, int(on)))
+
+    def debug_fetch(self, name: str, n: int, channels: int, positions: int) -> np.ndarray:
+        out = np.empty((n, channels, positions), dtype=np.float32)
+        self._check(self._lib.vqhip_debug_fetch(self._h, name.encode(), n, out.ctypes.data))
+        return out
+
+    def selftest_mfma(self) -> list:
+        out = (ctypes.c_int64 * 2)()
+        self._check(self._lib.vqhip_selftest_mfma(self._h, out))
+        return list(out)
+
+
+class IVQVAECodec:
+    """Abstract codec (IVQVAECodec.hpp:99-136)."""
+
+    @staticmethod
+    def create(config: CodecConfig, type: BackendType) -> Optional["IVQVAECodec"]:
+        """Factory (IVQVAECodec.cpp:76-110): any failure is reported on stderr and yields None."""
+        try:
+            if type == BackendType.HIP:
+                return HipBackend(config)
+            raise RuntimeError("Requested backend type is not available or disabled in the build configuration.")
+        except Exception as e:  # noqa: BLE001 — mirrors catch (const std::exception&)
+            print(f"Failed to create VQ-VAE backend: {e}", file=sys.stderr)
+            return None
+
+    def encode(self, leafBatch: TensorView) -> Tensor:
+        raise NotImplementedError
+
+    def decode(self, indices: TensorView) -> Tensor:
+        raise NotImplementedError
+
+    def getLatentShape(self) -> list:
+        raise NotImplementedError
+
+
+class HipBackend(IVQVAECodec):
+    """MI355X backend behind the reference's plugin surface (counterpart of TorchBackend,
+    src/backends/torch/TorchBackend.cpp)."""
+
+    def __init__(self, config: CodecConfig):
+        if config.device != CodecConfig.Device.CUDA:
+            raise RuntimeError("HIP backend requires Device::CUDA (GPU); there is no CPU path in this backend")
+        if isinstance(config.source, EmbeddedModel):
+            raise RuntimeError("no embedded weight pack in this build: pass a VQWPACK1 path or bytes as source")
+        self._codec = HipCodec(config.source, config.device_id)
+        self._latent = self._codec.latent_shape()
+
+    def encode(self, leafBatch: TensorView) -> Tensor:
+        if leafBatch.dtype != DataType.FLOAT32:
+            raise RuntimeError("encode expects FLOAT32 data.")          # TorchBackend.cpp:134-136
+        shape = list(leafBatch.shape)
+        if len(shape) != 5 or shape[1:] != [1, 8, 8, 8] or shape[0] < 1:
+            raise RuntimeError("encode expects shape [B,1,8,8,8].")
+        idx = self._codec.encode(np.asarray(leafBatch.data).reshape(shape[0], LEAF_VOXELS))
+        return Tensor(idx.reshape(-1).view(np.uint8), [shape[0]] + self._latent, DataType.UINT8)
+
+    def decode(self, indices: TensorView) -> Tensor:
+        if indices.dtype != DataType.UINT8:
+            raise RuntimeError("decode expects UINT8 data.")            # TorchBackend.cpp:167-169
+        shape = list(indices.shape)
+        if len(shape) != 4 or shape[1:] != self._latent or shape[0] < 1:
+            raise RuntimeError("decode expects shape [B,4,4,4].")
+        out = self._codec.decode(np.asarray(indices.data).reshape(shape[0], LATENT_VOXELS))
+        return Tensor(out.reshape(-1).view(np.uint8), [shape[0], 1, 8, 8, 8], DataType.FLOAT32)
+
+    def getLatentShape(self) -> list:
+        return list(self._latent)
+
+    @property
+    def raw(self) -> HipCodec:
+        return self._codec

@@ -1,0 +1,113 @@
+// vq_device.h — shared device-side definitions for the gfx950 leaf-codec kernels.
+//
+// Data layout in HBM ("leaf-tile" layout): leaves are grouped in tiles of LT = 32; inside a
+// tile the leaf index is (almost) the fastest axis so that one wavefront row of an MFMA
+// B-operand (32 leaves x 1 channel) is a contiguous 128-byte run:
+//
+//   act[tile][pos][C/4][32 leaves][4 channels]            (float; "L4" layout)
+//
+// i.e. element (leaf L, position p, channel c) lives at
+//   (((L/32)*NPOS + p)*(C/4) + c/4)*128 + (L%32)*4 + c%4 .
+// One lane reads/writes a float4 = 4 consecutive channels of one leaf; a 32-lane half-wave
+// covers 512 contiguous bytes.  The single-channel input uses act[tile][pos][32].
+// Per-leaf scalars (GroupNorm mean/rstd, channel sums) are stored [tile][k][32].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VQ_LT 32  // leaves per tile
+
+// D = A(32x2) * B(2x32) + C, exact fp32 (k-ordered fmaf chain), 64 cycles/SIMD.
+// Lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
+// result reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// D = A(16x4) * B(4x16) + C.  Lane l supplies A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];
+// result reg r is D[row = 4*(l>>4) + r][col = l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// exp with a fixed operation sequence shared with the CPU oracle's restatement
+// (oracle/vqvae_oracle.c vq_expf): Cephes-style polynomial, explicit fmaf only.
+__device__ __forceinline__ float vq_expf(float x)
+{
+    x = x > 88.0f ? 88.0f : x;
+    x = x < -87.0f ? -87.0f : x;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float e = __builtin_fmaf(p, r2, r) + 1.0f;
+    return __int_as_float(__float_as_int(e) + (((int)n) << 23));
+}
+__device__ __forceinline__ float vq_sigmoid(float x) { return 1.0f / (1.0f + vq_expf(-x)); }
+
+// GroupNorm statistics accumulator (fp64; same order as the oracle's gn_stats).
+struct GnAcc {
+    double s, q;
+    __device__ __forceinline__ void init() { s = 0.0; q = 0.0; }
+    __device__ __forceinline__ void add(float v)
+    {
+        const double d = (double)v;
+        s += d;
+        q = fma(d, d, q);
+    }
+};
+// mean / rstd from total sums over n = 2^k elements (fp64, rounded to fp32 at the end)
+__device__ __forceinline__ void gn_finish(double S, double Q, double inv_n, float& mean, float& rstd)
+{
+    const double m = S * inv_n, ex2 = Q * inv_n;
+    double var = fma(-m, m, ex2);
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+__device__ __forceinline__ double shfl_xor32_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, 32, 64);
+    hi = __shfl_xor(hi, 32, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// Squeeze-excite gate for one leaf (ChannelAttention, python/VQVAE_v2.py:213-228):
+// gate[c] = sigmoid( fc2[c][:] . relu( fc0 . mean ) ), mean[c] = csum[c]/64.
+// csum: this leaf's channel sums, element c at csum[c*32].  All lanes evaluate every channel
+// with wave-uniform weight addresses (scalar loads); callers pick the channels they need.
+template <int C>
+__device__ __forceinline__ void se_hidden(const float* __restrict__ csum, const float* __restrict__ fc0, float (&hid)[C / 4])
+{
+    constexpr int R = C / 4;
+#pragma unroll
+    for (int j = 0; j < R; ++j) hid[j] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float m = csum[c * VQ_LT] * (1.0f / 64.0f);
+#pragma unroll
+        for (int j = 0; j < R; ++j) hid[j] = __builtin_fmaf(fc0[j * C + c], m, hid[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) hid[j] = hid[j] > 0.0f ? hid[j] : 0.0f;
+}
+template <int C>
+__device__ __forceinline__ float se_gate(const float (&hid)[C / 4], const float* __restrict__ fc2, int c)
+{
+    constexpr int R = C / 4;
+    float a = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) a = __builtin_fmaf(fc2[c * R + j], hid[j], a);
+    return vq_sigmoid(a);
+}

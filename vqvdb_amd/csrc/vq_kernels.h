@@ -1,0 +1,775 @@
+// vq_kernels.h — gfx950 kernels of the VQ-VAE leaf codec (encode+quantize, decode).
+//
+// Common design: one WAVEFRONT owns one leaf tile (32 leaves) for a whole
+// layer and walks the output positions; the GEMM is  D[cout][leaf] += W[cout][k] * X[k][leaf]
+// with the weights as the MFMA A operand (pre-shuffled on the host into fragment order, read
+// from LDS with one ds_read_b128 per 4 MFMAs) and the activations as the B operand, read
+// straight from HBM/L2 in the leaf-tile layout (one coalesced float4 per lane per 4 MFMAs).
+// Because a whole MFMA tile sits at ONE spatial position, zero-padding taps are skipped
+// exactly (wave-uniform loop bounds) instead of being multiplied by zero.
+// Every accumulation order here is restated by oracle/vqvae_oracle.c; encode is bit-exact.
+#pragma once
+#include "vq_device.h"
+
+struct ConvArgs {
+    const float* in;         // L4 activations [tile][NPI][CIN/4][32][4]
+    float* out;              // L4 activations [tile][NPO][COUT/4][32][4] (or pixel-shuffled)
+    const float* wfrag;      // fragment-ordered weights
+    const float* bias_frag;  // bias in D-fragment order (mfma32) or plain (mfma16)
+    const float* skip;       // residual input (same layout as out)
+    const float* in_mean;    // [tile][GIN][32]
+    const float* in_rstd;
+    const float* in_gamma;   // [CIN]
+    const float* in_beta;
+    const float* se_csum;    // [tile][CIN][32] channel sums over the 64 positions
+    const float* se_fc0;     // [CIN/4][CIN]
+    const float* se_fc2;     // [CIN][CIN/4]
+    float* out_mean;         // [tile][GOUT][32]
+    float* out_rstd;
+    float* out_csum;         // [tile][COUT][32]
+    int n_tiles;
+};
+
+// ------------------------------------------------------------------------------------------
+// pack: host/leaf-major leaves [n][512] -> x[tile][512][32]   (VQVAECodec.cpp:36-59 layout in)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ leaves, float* __restrict__ xt, int64_t n_leaves)
+{
+    __shared__ float tile[32][65];
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int p0 = 0; p0 < 512; p0 += 64) {
+        // read: 32 leaves x 64 positions, position fastest (256-B runs per leaf)
+        for (int i = tid; i < 32 * 64; i += 256) {
+            const int l = i >> 6, p = i & 63;
+            const int64_t leaf = (int64_t)t * 32 + l;
+            tile[l][p] = leaf < n_leaves ? leaves[leaf * 512 + p0 + p] : 0.0f;
+        }
+        __syncthreads();
+        for (int i = tid; i < 32 * 64; i += 256) {
+            const int p = i >> 5, l = i & 31;
+            xt[((int64_t)t * 512 + p0 + p) * 32 + l] = tile[l][p];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E1: Conv3d(1->16,k3,p1) @8^3 (VQVAE_v2.py:235) + GroupNorm(4,16) statistics (:236).
+// 16x16x4 MFMA: rows = 16 couts, cols = 16 leaves, K = (kd,kh) x {kw0,kw1,kw2,pad}.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_k(ConvArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= A.n_tiles) return;
+    const int jj = lane & 15, q4 = lane >> 4;
+    float w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = A.wfrag[t * 64 + lane];
+    const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
+    const float* x = A.in + (size_t)tile * 512 * 32;
+    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32;
+    GnAcc st[2];
+    st[0].init();
+    st[1].init();
+    for (int od = 0; od < 8; ++od)
+        for (int oh = 0; oh < 8; ++oh)
+            for (int ow = 0; ow < 8; ++ow) {
+                f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                const int iw = ow + q4 - 1;
+                const bool okw = (q4 < 3) && iw >= 0 && iw < 8;
+                const int iwc = okw ? iw : 0;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const int id = od + kd - 1;
+                    if (id < 0 || id > 7) continue;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int ih = oh + kh - 1;
+                        if (ih < 0 || ih > 7) continue;
+                        const float* xp = x + (size_t)((id * 8 + ih) * 8 + iwc) * 32 + jj;
+                        const float b0 = okw ? xp[0] : 0.0f;
+                        const float b1 = okw ? xp[16] : 0.0f;
+                        acc[0] = mfma16(w[kd * 3 + kh], b0, acc[0]);
+                        acc[1] = mfma16(w[kd * 3 + kh], b1, acc[1]);
+                    }
+                }
+                const int po = (od * 8 + oh) * 8 + ow;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f32x4 v = acc[s] + bias4;
+                    out4[((size_t)po * 4 + q4) * 32 + 16 * s + jj] = v;
+                    st[s].add(v.x);
+                    st[s].add(v.y);
+                    st[s].add(v.z);
+                    st[s].add(v.w);
+                }
+            }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float m, r;
+        gn_finish(st[s].s, st[s].q, 1.0 / 2048.0, m, r);
+        A.out_mean[((size_t)tile * 4 + q4) * 32 + 16 * s + jj] = m;
+        A.out_rstd[((size_t)tile * 4 + q4) * 32 + 16 * s + jj] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Elementwise y = relu(GroupNorm_GIN(x)) + statistics of y for the next GroupNorm(8, C).
+// Used after both stems (VQVAE_v2.py:236-237 -> ResidualBlock.gn1 :205; :258-259 -> :205).
+// Lane (leaf j, half h) owns channels [h*C/2, (h+1)*C/2).
+// ------------------------------------------------------------------------------------------
+template <int C, int NP, int GIN>
+__global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
+{
+    constexpr int NG = C / 4, NGL = NG / 2, CPGI = C / GIN, CPGO = C / 8;
+    static_assert(CPGO == 2 || CPGO == 8, "output groups of 2 or 8 channels");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= A.n_tiles) return;
+    const int j = lane & 31, h = lane >> 5;
+    float ia[NGL][4], ib[NGL][4];
+#pragma unroll
+    for (int gl = 0; gl < NGL; ++gl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (h * NGL + gl) * 4 + i;
+            const int g = c / CPGI;
+            const float mean = A.in_mean[((size_t)tile * GIN + g) * 32 + j];
+            const float rstd = A.in_rstd[((size_t)tile * GIN + g) * 32 + j];
+            ia[gl][i] = rstd * A.in_gamma[c];
+            ib[gl][i] = __builtin_fmaf(-mean, ia[gl][i], A.in_beta[c]);
+        }
+    constexpr int NACC = (CPGO == 2) ? NGL * 2 : NGL;
+    GnAcc st[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) st[k].init();
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NP * NG * 32 + (size_t)h * NGL * 32 + j;
+    f32x4* out4 = (f32x4*)A.out + (size_t)tile * NP * NG * 32 + (size_t)h * NGL * 32 + j;
+#pragma unroll 2
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int gl = 0; gl < NGL; ++gl) {
+            f32x4 v = in4[((size_t)p * NG + gl) * 32];
+            f32x4 y;
+            y.x = fmaxf(__builtin_fmaf(v.x, ia[gl][0], ib[gl][0]), 0.0f);
+            y.y = fmaxf(__builtin_fmaf(v.y, ia[gl][1], ib[gl][1]), 0.0f);
+            y.z = fmaxf(__builtin_fmaf(v.z, ia[gl][2], ib[gl][2]), 0.0f);
+            y.w = fmaxf(__builtin_fmaf(v.w, ia[gl][3], ib[gl][3]), 0.0f);
+            out4[((size_t)p * NG + gl) * 32] = y;
+            if (CPGO == 2) {
+                st[gl * 2 + 0].add(y.x);
+                st[gl * 2 + 0].add(y.y);
+                st[gl * 2 + 1].add(y.z);
+                st[gl * 2 + 1].add(y.w);
+            } else {
+                st[gl].add(y.x);
+                st[gl].add(y.y);
+                st[gl].add(y.z);
+                st[gl].add(y.w);
+            }
+        }
+    }
+    const double inv_n = 1.0 / (double)(CPGO * NP);
+    if (CPGO == 2) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            float m, r;
+            gn_finish(st[k].s, st[k].q, inv_n, m, r);
+            const int g = (h * NGL) * 2 + k;
+            A.out_mean[((size_t)tile * 8 + g) * 32 + j] = m;
+            A.out_rstd[((size_t)tile * 8 + g) * 32 + j] = r;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NACC / 2; ++k) {
+            float m, r;
+            gn_finish(st[2 * k].s + st[2 * k + 1].s, st[2 * k].q + st[2 * k + 1].q, inv_n, m, r);
+            const int g = (h * NGL) / 2 + k;
+            A.out_mean[((size_t)tile * 8 + g) * 32 + j] = m;
+            A.out_rstd[((size_t)tile * 8 + g) * 32 + j] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E4/E6: Conv3d(16->16,k3,p1) @8^3 inside ResidualBlock(16) (VQVAE_v2.py:190-210, :238).
+// 16x16x4 MFMA (rows 16 couts, cols 16 leaves, K = 4 channels/step, order P16); one wave owns
+// a 32-leaf tile as two 16-leaf sub-tiles and register-blocks a full row of 8 outputs so each
+// loaded input float4 feeds up to 3 taps.  Input transform relu(GroupNorm(8,16)) is applied
+// once per loaded element.  Weights (27 KB) stay resident in LDS.
+// ------------------------------------------------------------------------------------------
+template <bool RESID, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A)
+{
+    __shared__ f32x4 wl[27 * 64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) wl[i] = ((const f32x4*)A.wfrag)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= A.n_tiles) return;
+    const int jj = lane & 15, q4 = lane >> 4;
+    float ia[2][4], ib[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q4 + i, g = c >> 1;
+            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + 16 * s + jj];
+            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + 16 * s + jj];
+            ia[s][i] = rstd * A.in_gamma[c];
+            ib[s][i] = __builtin_fmaf(-mean, ia[s][i], A.in_beta[c]);
+        }
+    const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+    const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
+    GnAcc st[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        st[s][0].init();
+        st[s][1].init();
+    }
+    for (int od = 0; od < 8; ++od)
+        for (int oh = 0; oh < 8; ++oh) {
+            f32x4 acc[8][2];
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) {
+                acc[ow][0] = (f32x4){0, 0, 0, 0};
+                acc[ow][1] = (f32x4){0, 0, 0, 0};
+            }
+            const int kd0 = od == 0 ? 1 : 0, kd1 = od == 7 ? 2 : 3;
+            const int kh0 = oh == 0 ? 1 : 0, kh1 = oh == 7 ? 2 : 3;
+            for (int kd = kd0; kd < kd1; ++kd)
+                for (int kh = kh0; kh < kh1; ++kh) {
+                    const int id = od + kd - 1, ih = oh + kh - 1;
+                    f32x4 xin[8][2];
+#pragma unroll
+                    for (int iw = 0; iw < 8; ++iw)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            f32x4 v = in4[((size_t)((id * 8 + ih) * 8 + iw) * 4) * 32 + 16 * s];
+                            v.x = fmaxf(__builtin_fmaf(v.x, ia[s][0], ib[s][0]), 0.0f);
+                            v.y = fmaxf(__builtin_fmaf(v.y, ia[s][1], ib[s][1]), 0.0f);
+                            v.z = fmaxf(__builtin_fmaf(v.z, ia[s][2], ib[s][2]), 0.0f);
+                            v.w = fmaxf(__builtin_fmaf(v.w, ia[s][3], ib[s][3]), 0.0f);
+                            xin[iw][s] = v;
+                        }
+                    const f32x4* wt = wl + (kd * 3 + kh) * 3 * 64 + lane;
+                    const f32x4 w0 = wt[0], w1 = wt[64], w2 = wt[128];
+#pragma unroll
+                    for (int ow = 0; ow < 8; ++ow)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int iw = ow + kw - 1;
+                            if (iw < 0 || iw > 7) continue;
+                            const f32x4 w = kw == 0 ? w0 : (kw == 1 ? w1 : w2);
+#pragma unroll
+                            for (int s = 0; s < 2; ++s) {
+                                acc[ow][s] = mfma16(w.x, xin[iw][s].x, acc[ow][s]);
+                                acc[ow][s] = mfma16(w.y, xin[iw][s].y, acc[ow][s]);
+                                acc[ow][s] = mfma16(w.z, xin[iw][s].z, acc[ow][s]);
+                                acc[ow][s] = mfma16(w.w, xin[iw][s].w, acc[ow][s]);
+                            }
+                        }
+                }
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const size_t o = ((size_t)((od * 8 + oh) * 8 + ow) * 4) * 32 + 16 * s;
+                    f32x4 v = acc[ow][s] + bias4;
+                    if (RESID) {
+                        const f32x4 sk = skip4[o];
+                        const f32x4 u = v * 0.1f;
+                        v = sk + u;
+                    }
+                    out4[o] = v;
+                    if (STATS) {
+                        st[s][0].add(v.x);
+                        st[s][0].add(v.y);
+                        st[s][1].add(v.z);
+                        st[s][1].add(v.w);
+                    }
+                }
+        }
+    if (STATS) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float m, r;
+                gn_finish(st[s][k].s, st[s][k].q, 1.0 / 1024.0, m, r);
+                A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * s + jj] = m;
+                A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * s + jj] = r;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic leaf-tile conv on the 32x32x2 fp32 MFMA: rows = 32 couts, cols = 32 leaves, K order P8.
+// One wave owns one tile and walks the NPO output positions; per (position, valid tap) it
+// reads CIN/8 float4 of activations per lane and, per 32-cout tile, one ds_read_b128 of
+// weights per 4 MFMAs.  Weights are either fully LDS-resident (STREAM=false: encoder 4^3
+// layers, <=128 KB) or re-staged per (position, tap) step, all waves of the workgroup in
+// lock-step on the same step (STREAM=true: decoder layers, 0.4-1.8 MB of weights).
+//   INMODE 0: raw input      1: relu(GroupNorm(GIN)) on load      2: squeeze-excite gate on load
+//   RESID  : out = skip + 0.1*(acc+bias)        GOUT: GroupNorm statistics of the output
+//   CSUM   : per-channel sums of the output (feeds ChannelAttention of the next kernel)
+//   PIXSHUF: store through PixelShuffle3D(2) (VQVAE_v2.py:172-187) into a 32-channel 8^3 tensor
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int NW, bool STREAM, int INMODE, int GIN,
+          bool RESID, int GOUT, bool CSUM, bool PIXSHUF>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* lds = (f32x4*)smem_raw;
+    constexpr int NU = CIN / 8, NMT = COUT / 32, NPI = SI * SI * SI, NPO = SO * SO * SO, KT = KS * KS * KS;
+    constexpr int WTAP = NU * NMT * 64;  // float4 per tap
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, q = lane >> 5;
+    int tile = blockIdx.x * NW + wave;
+    const bool active = tile < A.n_tiles;
+    if (!active) tile = A.n_tiles - 1;
+    const f32x4* wg4 = (const f32x4*)A.wfrag;
+    if (!STREAM) {
+        for (int i = threadIdx.x; i < KT * WTAP; i += NW * 64) lds[i] = wg4[i];
+        __syncthreads();
+        if (!active) return;
+    }
+
+    // ---- input transform, per lane: channels cin = 8u + 4q + i ----
+    float ta[INMODE == 0 ? 1 : NU][4], tb[INMODE == 1 ? NU : 1][4];
+    if (INMODE == 1) {
+        constexpr int CPGI = CIN / (GIN > 0 ? GIN : 1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 8 * u + 4 * q + i, g = c / CPGI;
+                const float mean = A.in_mean[((size_t)tile * GIN + g) * 32 + j];
+                const float rstd = A.in_rstd[((size_t)tile * GIN + g) * 32 + j];
+                ta[u][i] = rstd * A.in_gamma[c];
+                tb[u][i] = __builtin_fmaf(-mean, ta[u][i], A.in_beta[c]);
+            }
+    } else if (INMODE == 2) {
+        float hid[CIN / 4];
+        se_hidden<CIN>(A.se_csum + (size_t)tile * CIN * 32 + j, A.se_fc0, hid);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ta[u][i] = se_gate<CIN>(hid, A.se_fc2, 8 * u + 4 * q + i);
+    }
+
+    constexpr int NST = (GOUT > 0) ? NMT * 4 : 1;
+    GnAcc st[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) st[k].init();
+    float cs[CSUM ? NMT : 1][16];
+    if (CSUM) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[mt][r] = 0.0f;
+    }
+
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;
+    const f32x4* bf4 = (const f32x4*)A.bias_frag;
+
+    for (int od = 0; od < SO; ++od)
+        for (int oh = 0; oh < SO; ++oh)
+            for (int ow = 0; ow < SO; ++ow) {
+                f32x16 acc[NMT];
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+                const int kd0 = max(0, PAD - od * STRIDE), kd1 = min(KS, SI + PAD - od * STRIDE);
+                const int kh0 = max(0, PAD - oh * STRIDE), kh1 = min(KS, SI + PAD - oh * STRIDE);
+                const int kw0 = max(0, PAD - ow * STRIDE), kw1 = min(KS, SI + PAD - ow * STRIDE);
+                for (int kd = kd0; kd < kd1; ++kd)
+                    for (int kh = kh0; kh < kh1; ++kh)
+                        for (int kw = kw0; kw < kw1; ++kw) {
+                            const int id = od * STRIDE - PAD + kd, ih = oh * STRIDE - PAD + kh, iw = ow * STRIDE - PAD + kw;
+                            const int ip = (id * SI + ih) * SI + iw;
+                            const int tap = (kd * KS + kh) * KS + kw;
+                            const f32x4* wl;
+                            if (STREAM) {
+                                __syncthreads();
+                                for (int i = threadIdx.x; i < WTAP; i += NW * 64) lds[i] = wg4[(size_t)tap * WTAP + i];
+                                __syncthreads();
+                                wl = lds + lane;
+                            } else {
+                                wl = lds + (size_t)tap * WTAP + lane;
+                            }
+                            const f32x4* bp = in4 + (size_t)ip * (CIN / 4) * 32;
+#pragma unroll
+                            for (int u = 0; u < NU; ++u) {
+                                f32x4 b = bp[u * 64];
+                                if (INMODE == 1) {
+                                    b.x = fmaxf(__builtin_fmaf(b.x, ta[u][0], tb[u][0]), 0.0f);
+                                    b.y = fmaxf(__builtin_fmaf(b.y, ta[u][1], tb[u][1]), 0.0f);
+                                    b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
+                                    b.w = fmaxf(__builtin_fmaf(b.w, ta[u][3], tb[u][3]), 0.0f);
+                                } else if (INMODE == 2) {
+                                    b.x = b.x * ta[u][0];
+                                    b.y = b.y * ta[u][1];
+                                    b.z = b.z * ta[u][2];
+                                    b.w = b.w * ta[u][3];
+                                }
+#pragma unroll
+                                for (int mt = 0; mt < NMT; ++mt) {
+                                    const f32x4 w = wl[(u * NMT + mt) * 64];
+                                    acc[mt] = mfma32(w.x, b.x, acc[mt]);
+                                    acc[mt] = mfma32(w.y, b.y, acc[mt]);
+                                    acc[mt] = mfma32(w.z, b.z, acc[mt]);
+                                    acc[mt] = mfma32(w.w, b.w, acc[mt]);
+                                }
+                            }
+                        }
+                // ---- epilogue for this output position ----
+                const int po = (od * SO + oh) * SO + ow;
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bias = bf4[(mt * 2 + q) * 4 + g];
+                        f32x4 v;
+                        v.x = acc[mt][4 * g + 0] + bias.x;
+                        v.y = acc[mt][4 * g + 1] + bias.y;
+                        v.z = acc[mt][4 * g + 2] + bias.z;
+                        v.w = acc[mt][4 * g + 3] + bias.w;
+                        // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
+                        const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
+                        if (RESID) {
+                            const f32x4 sk = ((const f32x4*)A.skip)[o];
+                            const f32x4 u = v * 0.1f;
+                            v = sk + u;
+                        }
+                        if (!PIXSHUF && active) ((f32x4*)A.out)[o] = v;
+                        if (GOUT > 0) {
+                            st[mt * 4 + g].add(v.x);
+                            st[mt * 4 + g].add(v.y);
+                            st[mt * 4 + g].add(v.z);
+                            st[mt * 4 + g].add(v.w);
+                        }
+                        if (CSUM) {
+                            cs[mt][4 * g + 0] = cs[mt][4 * g + 0] + v.x;
+                            cs[mt][4 * g + 1] = cs[mt][4 * g + 1] + v.y;
+                            cs[mt][4 * g + 2] = cs[mt][4 * g + 2] + v.z;
+                            cs[mt][4 * g + 3] = cs[mt][4 * g + 3] + v.w;
+                        }
+                        if (PIXSHUF) acc[mt][4 * g + 0] = v.x, acc[mt][4 * g + 1] = v.y, acc[mt][4 * g + 2] = v.z, acc[mt][4 * g + 3] = v.w;
+                    }
+                    if (PIXSHUF && active) {
+                        // cout = 32mt + 8g + 4q + i  ->  oc = cout/8 = 4mt + g, sub = cout%8 = 4q + i
+                        // out[oc][2d+q][2h+(i>>1)][2w+(i&1)]; the 4 g's form L4 group mt of the 32-ch tensor.
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int p8 = ((2 * od + q) * 8 + 2 * oh + (i >> 1)) * 8 + 2 * ow + (i & 1);
+                            f32x4 v;
+                            v.x = acc[mt][i];
+                            v.y = acc[mt][4 + i];
+                            v.z = acc[mt][8 + i];
+                            v.w = acc[mt][12 + i];
+                            ((f32x4*)A.out)[(((size_t)tile * 512 + p8) * 8 + mt) * 32 + j] = v;
+                        }
+                    }
+                }
+            }
+    if (!active) return;
+    if (GOUT > 0) {
+        constexpr int CPGO = COUT / (GOUT > 0 ? GOUT : 1);
+        static_assert(GOUT == 0 || CPGO == 4 || CPGO == 8, "stats groups of 4 or 8 channels");
+        const double inv_n = 1.0 / (double)(CPGO * NPO);
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double S = st[mt * 4 + g].s, Q = st[mt * 4 + g].q;
+                if (CPGO == 8) {
+                    S = S + shfl_xor32_f64(S);
+                    Q = Q + shfl_xor32_f64(Q);
+                }
+                float m, r;
+                gn_finish(S, Q, inv_n, m, r);
+                const int grp = CPGO == 4 ? 8 * mt + 2 * g + q : 4 * mt + g;
+                if (CPGO == 4 || q == 0) {
+                    A.out_mean[((size_t)tile * GOUT + grp) * 32 + j] = m;
+                    A.out_rstd[((size_t)tile * GOUT + grp) * 32 + j] = r;
+                }
+            }
+    }
+    if (CSUM) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q;
+                A.out_csum[((size_t)tile * COUT + co) * 32 + j] = cs[mt][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Encoder tail: ChannelAttention(32) (VQVAE_v2.py:242) -> Conv3d(32->128,k1) (:243) -> nearest
+// codebook row (:358-367).  Per position the 128-channel latent never leaves registers: the
+// proj MFMA result (D fragment, channel = 32t + (r&3) + 8(r>>2) + 4q) is fed back as the B
+// operand of the distance MFMAs with the codebook pre-shuffled to the same K order.
+// Codebook (128 KB) + proj weights (16 KB) stay in LDS.
+// ------------------------------------------------------------------------------------------
+struct VqArgs {
+    const float* in;        // x11 L4 [tile][64][8][32][4]
+    const float* se_csum;   // [tile][32][32]
+    const float* se_fc0;    // [8][32]
+    const float* se_fc2;    // [32][8]
+    const float* wproj;     // frag [u=4][mt=4][64][4]
+    const float* bproj;     // D-fragment order [(mt*2+q)*16 + r]
+    const float* efrag;     // frag [u=16][ct=8][64][4]
+    const float* ee_frag;   // [(ct*2+q)*16 + r]
+    uint8_t* idx;           // [n_leaves][64]
+    float* z_dbg;           // optional L4 [tile][64][32][32][4]
+    int64_t n_leaves;
+    int n_tiles;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* ldsE = (f32x4*)smem_raw;          // 16*8*64 float4 = 128 KB
+    f32x4* ldsP = ldsE + 16 * 8 * 64;        // 4*4*64 float4  = 16 KB
+    for (int i = threadIdx.x; i < 16 * 8 * 64; i += NW * 64) ldsE[i] = ((const f32x4*)A.efrag)[i];
+    for (int i = threadIdx.x; i < 4 * 4 * 64; i += NW * 64) ldsP[i] = ((const f32x4*)A.wproj)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * NW + wave;
+    if (tile >= A.n_tiles) return;
+    const int j = lane & 31, q = lane >> 5;
+    float gate[4][4];
+    {
+        float hid[8];
+        se_hidden<32>(A.se_csum + (size_t)tile * 32 * 32 + j, A.se_fc0, hid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate[u][i] = se_gate<32>(hid, A.se_fc2, 8 * u + 4 * q + i);
+    }
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 8 * 32 + q * 32 + j;
+    const f32x4* bp4 = (const f32x4*)A.bproj;
+    const f32x4* ee4 = (const f32x4*)A.ee_frag;
+    const int64_t leaf = (int64_t)tile * 32 + j;
+    for (int p = 0; p < 64; ++p) {
+        f32x16 z[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[t][r] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 b = in4[((size_t)p * 8 + 2 * u) * 32];
+            b.x = b.x * gate[u][0];
+            b.y = b.y * gate[u][1];
+            b.z = b.z * gate[u][2];
+            b.w = b.w * gate[u][3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 w = ldsP[(u * 4 + t) * 64 + lane];
+                z[t] = mfma32(w.x, b.x, z[t]);
+                z[t] = mfma32(w.y, b.y, z[t]);
+                z[t] = mfma32(w.z, b.z, z[t]);
+                z[t] = mfma32(w.w, b.w, z[t]);
+            }
+        }
+        float zzp = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = bp4[(t * 2 + q) * 4 + g];
+                z[t][4 * g + 0] = z[t][4 * g + 0] + bias.x;
+                z[t][4 * g + 1] = z[t][4 * g + 1] + bias.y;
+                z[t][4 * g + 2] = z[t][4 * g + 2] + bias.z;
+                z[t][4 * g + 3] = z[t][4 * g + 3] + bias.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zzp = __builtin_fmaf(z[t][4 * g + i], z[t][4 * g + i], zzp);
+                if (A.z_dbg) {
+                    f32x4 v;
+                    v.x = z[t][4 * g + 0], v.y = z[t][4 * g + 1], v.z = z[t][4 * g + 2], v.w = z[t][4 * g + 3];
+                    ((f32x4*)A.z_dbg)[(((size_t)tile * 64 + p) * 32 + 8 * t + 2 * g + q) * 32 + j] = v;
+                }
+            }
+        const float zzo = __shfl_xor(zzp, 32, 64);
+        const float zz = q == 0 ? zzp + zzo : zzo + zzp;  // partial(c&4==0) + partial(c&4!=0)
+        float best = __builtin_inff();
+        int bk = 0;
+        for (int ct = 0; ct < 8; ++ct) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 e = ldsE[((4 * t + g) * 8 + ct) * 64 + lane];
+                    d = mfma32(e.x, z[t][4 * g + 0], d);
+                    d = mfma32(e.y, z[t][4 * g + 1], d);
+                    d = mfma32(e.z, z[t][4 * g + 2], d);
+                    d = mfma32(e.w, z[t][4 * g + 3], d);
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);  // keep LDS reads from piling up (VGPR budget)
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ee = ee4[(ct * 2 + q) * 4 + g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float een = i == 0 ? ee.x : (i == 1 ? ee.y : (i == 2 ? ee.z : ee.w));
+                    const float t1 = zz + een;
+                    const float dist = t1 - 2.0f * d[4 * g + i];
+                    const int k = 32 * ct + i + 8 * g + 4 * q;
+                    if (dist < best) {
+                        best = dist;
+                        bk = k;
+                    }
+                }
+            }
+        }
+        const float ob = __shfl_xor(best, 32, 64);
+        const int ok = __shfl_xor(bk, 32, 64);
+        if (ob < best || (ob == best && ok < bk)) bk = ok;
+        if (q == 0 && leaf < A.n_leaves) A.idx[leaf * 64 + p] = (uint8_t)bk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// D0: embedding gather (VQVAE_v2.py:373-375): q[leaf][c][pos] = E[idx[leaf][pos]][c], L4 layout.
+// One wave per (tile, position); lane (leaf j, half h) copies every other float4 of its row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_codes_k(const uint8_t* __restrict__ idx, const float* __restrict__ E,
+                                                      float* __restrict__ qout, int64_t n_leaves, int n_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile = w >> 6;
+    const int p = (int)(w & 63);
+    if (tile >= n_tiles) return;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t leaf = tile * 32 + j;
+    const int k = leaf < n_leaves ? idx[leaf * 64 + p] : 0;
+    const f32x4* e4 = (const f32x4*)E + (size_t)k * 32;
+    f32x4* o4 = (f32x4*)qout + ((size_t)tile * 64 + p) * 32 * 32 + j;
+#pragma unroll 4
+    for (int g = h; g < 32; g += 2) o4[(size_t)g * 32] = e4[g];
+}
+
+// ------------------------------------------------------------------------------------------
+// D10/D11: Conv3d(32->1,k3,p1) @8^3 + sigmoid (VQVAE_v2.py:268,275), output leaf-major
+// [n][512] as the orchestrator's unpack loop expects (VQVAECodec.cpp:182-192).
+// One output channel -> no matrix shape: fp32 VALU, lane = leaf (two tiles per wave), a row of 8
+// outputs per lane in registers, weights through wave-uniform (scalar) loads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_conv_k(const float* __restrict__ ps, const float* __restrict__ wfin /*[27][32]*/,
+                                                    float bias, float* __restrict__ out, int64_t n_leaves, int n_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile0 = (blockIdx.x * 4 + wave) * 2;
+    if (tile0 >= n_tiles) return;
+    int tile = tile0 + (lane >> 5);
+    const bool act = tile < n_tiles;
+    if (!act) tile = n_tiles - 1;
+    const int j = lane & 31;
+    const f32x4* in4 = (const f32x4*)ps + (size_t)tile * 512 * 8 * 32 + j;
+    const f32x4* w4 = (const f32x4*)wfin;
+    const int64_t leaf = (int64_t)tile * 32 + j;
+    for (int od = 0; od < 8; ++od)
+        for (int oh = 0; oh < 8; ++oh) {
+            float acc[8];
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) acc[ow] = 0.0f;
+            const int kd0 = od == 0 ? 1 : 0, kd1 = od == 7 ? 2 : 3;
+            const int kh0 = oh == 0 ? 1 : 0, kh1 = oh == 7 ? 2 : 3;
+            for (int kd = kd0; kd < kd1; ++kd)
+                for (int kh = kh0; kh < kh1; ++kh) {
+                    const int id = od + kd - 1, ih = oh + kh - 1;
+                    const f32x4* wt = w4 + (kd * 3 + kh) * 3 * 8;
+#pragma unroll
+                    for (int iw = 0; iw < 8; ++iw)
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            const f32x4 x = in4[((size_t)((id * 8 + ih) * 8 + iw) * 8 + g) * 32];
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) {
+                                const int ow = iw - kw + 1;
+                                if (ow < 0 || ow > 7) continue;
+                                const f32x4 w = wt[kw * 8 + g];
+                                acc[ow] = __builtin_fmaf(w.x, x.x, acc[ow]);
+                                acc[ow] = __builtin_fmaf(w.y, x.y, acc[ow]);
+                                acc[ow] = __builtin_fmaf(w.z, x.z, acc[ow]);
+                                acc[ow] = __builtin_fmaf(w.w, x.w, acc[ow]);
+                            }
+                        }
+                }
+            if (act && leaf < n_leaves) {
+                f32x4 o0, o1;
+                o0.x = vq_sigmoid(acc[0] + bias);
+                o0.y = vq_sigmoid(acc[1] + bias);
+                o0.z = vq_sigmoid(acc[2] + bias);
+                o0.w = vq_sigmoid(acc[3] + bias);
+                o1.x = vq_sigmoid(acc[4] + bias);
+                o1.y = vq_sigmoid(acc[5] + bias);
+                o1.z = vq_sigmoid(acc[6] + bias);
+                o1.w = vq_sigmoid(acc[7] + bias);
+                f32x4* o = (f32x4*)(out + leaf * 512 + (od * 8 + oh) * 8);
+                o[0] = o0;
+                o[1] = o1;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hardware-assumption probe: fp32 MFMA == k-ordered fmaf chain (cdna guide §3).
+// ------------------------------------------------------------------------------------------
+__global__ void mfma_probe_k(const float* __restrict__ a32, const float* __restrict__ b32, const float* __restrict__ a16,
+                             const float* __restrict__ b16, int ksteps, unsigned long long* mism)
+{
+    const int lane = threadIdx.x;
+    // 32x32x2: A[32][2*ksteps] row-major, B[2*ksteps][32]
+    {
+        f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int s = 0; s < ksteps; ++s) {
+            const int k = 2 * s + (lane >> 5);
+            acc = mfma32(a32[(lane & 31) * 2 * ksteps + k], b32[k * 32 + (lane & 31)], acc);
+        }
+        unsigned long long bad = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+            float ref = 0.0f;
+            for (int k = 0; k < 2 * ksteps; ++k) ref = __builtin_fmaf(a32[row * 2 * ksteps + k], b32[k * 32 + col], ref);
+            bad += (__float_as_uint(ref) != __float_as_uint(acc[r]));
+        }
+        if (bad) atomicAdd(mism, bad);
+    }
+    {
+        f32x4 acc = {0, 0, 0, 0};
+        for (int s = 0; s < ksteps; ++s) {
+            const int k = 4 * s + (lane >> 4);
+            acc = mfma16(a16[(lane & 15) * 4 * ksteps + k], b16[k * 16 + (lane & 15)], acc);
+        }
+        unsigned long long bad = 0;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r, col = lane & 15;
+            float ref = 0.0f;
+            for (int k = 0; k < 4 * ksteps; ++k) ref = __builtin_fmaf(a16[row * 4 * ksteps + k], b16[k * 16 + col], ref);
+            bad += (__float_as_uint(ref) != __float_as_uint(acc[r]));
+        }
+        if (bad) atomicAdd(mism + 1, bad);
+    }
+}

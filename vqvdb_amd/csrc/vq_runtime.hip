@@ -1,0 +1,787 @@
+// vq_runtime.hip — host runtime and C ABI of libvqvdb_hip.so (include/vqvdb_hip.h).
+//
+// One vqhip_codec = one device context: fragment-ordered weights resident in HBM, a
+// workspace of leaf-tile activations sized for one chunk of leaves, a compute stream and
+// pinned staging buffers for the host-pointer entry points.  No PyTorch / ONNX / CPU
+// fallback: if HIP is unavailable every entry point fails with VQHIP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vqvdb_hip.h"
+#include "vq_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct PackTensor {
+    std::vector<uint32_t> dims;
+    const float* data = nullptr;
+    size_t count = 0;
+};
+
+struct KernelTimer {
+    std::string name;
+    hipEvent_t start, stop;
+    int64_t leaves;
+};
+
+struct KernelInfo {
+    double flops, eff_flops;
+};
+
+// nominal / effective (padding taps excluded) FLOPs per leaf of each compute kernel
+const std::map<std::string, KernelInfo>& kernel_info()
+{
+    static const std::map<std::string, KernelInfo> m = {
+        {"enc_conv_first", {2.0 * 221184, 2.0 * 221184 * 0.7703}},
+        {"enc_res16_conv1", {2.0 * 3538944, 2.0 * 3538944 * 0.7703}},
+        {"enc_res16_conv2", {2.0 * 3538944, 2.0 * 3538944 * 0.7703}},
+        {"enc_down", {2.0 * 2097152, 2.0 * 2097152 * 0.669922}},
+        {"enc_res32_conv1", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
+        {"enc_res32_conv2", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
+        {"enc_proj_vq", {2.0 * (262144 + 2097152 + 512), 2.0 * (262144 + 2097152 + 512)}},
+        {"dec_stem", {2.0 * 14155776, 2.0 * 14155776 * 0.578704}},
+        {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
+        {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
+        {"dec_up_conv", {2.0 * (28311552 + 2048), 2.0 * (28311552 * 0.578704 + 2048)}},
+        {"dec_final", {2.0 * 442368, 2.0 * 442368 * 0.7703}},
+    };
+    return m;
+}
+
+}  // namespace
+
+struct vqhip_codec {
+    int device = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    int64_t chunk = 65536;
+
+    // device weights
+    std::map<std::string, float*> dw;
+    float e_final_bias = 0.0f;
+
+    // workspace
+    int64_t ws_tiles = 0;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::map<std::string, float*> act;  // named activation buffers inside ws
+    std::map<std::string, std::pair<int, int>> act_shape;
+
+    // staging
+    void* pin_in = nullptr;
+    void* pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    float* dev_leaves = nullptr;  // chunk * 512 floats
+    uint8_t* dev_idx = nullptr;   // chunk * 64 bytes
+    int64_t dev_io_leaves = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<KernelTimer> timers;
+
+    bool debug = false;
+};
+
+namespace {
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return VQHIP_ERR_DEVICE;                                                            \
+        }                                                                                       \
+    } while (0)
+
+int fail(vqhip_codec* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+// ---------------- weight pack (vqvdb_amd/weightpack.py) ----------------
+bool parse_pack(const unsigned char* p, size_t n, std::map<std::string, PackTensor>& out, std::string& err)
+{
+    if (n < 16 || std::memcmp(p, "VQWPACK1", 8) != 0) {
+        err = "weight pack: bad magic (expected VQWPACK1)";
+        return false;
+    }
+    uint32_t nt;
+    std::memcpy(&nt, p + 8, 4);
+    const size_t ent = 108;
+    if (16 + (size_t)nt * ent > n) {
+        err = "weight pack: truncated table";
+        return false;
+    }
+    for (uint32_t i = 0; i < nt; ++i) {
+        const unsigned char* e = p + 16 + (size_t)i * ent;
+        char name[65];
+        std::memcpy(name, e, 64);
+        name[64] = 0;
+        uint32_t ndim, dims[6];
+        uint64_t off, cnt;
+        std::memcpy(&ndim, e + 64, 4);
+        std::memcpy(dims, e + 68, 24);
+        std::memcpy(&off, e + 92, 8);
+        std::memcpy(&cnt, e + 100, 8);
+        if (ndim > 6 || off + cnt * 4 > n || (off & 3)) {
+            err = std::string("weight pack: tensor '") + name + "' out of bounds";
+            return false;
+        }
+        PackTensor t;
+        t.dims.assign(dims, dims + ndim);
+        t.data = reinterpret_cast<const float*>(p + off);
+        t.count = cnt;
+        out[name] = t;
+    }
+    return true;
+}
+
+const PackTensor* need(const std::map<std::string, PackTensor>& pk, const char* name, std::initializer_list<uint32_t> dims, std::string& err)
+{
+    auto it = pk.find(name);
+    if (it == pk.end()) {
+        err = std::string("weight pack: missing tensor '") + name + "'";
+        return nullptr;
+    }
+    if (it->second.dims != std::vector<uint32_t>(dims)) {
+        err = std::string("weight pack: tensor '") + name + "' has unexpected shape";
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// ---------------- fragment repacks (host, once at create) ----------------
+// 32x32x2 A-fragments: [tap][u][mt][lane][i] = W[cout = 32mt + (lane&31)][cin = 8u + 4(lane>>5) + i][tap]
+std::vector<float> frag32(const float* W, int COUT, int CIN, int KT)
+{
+    const int NU = CIN / 8, NMT = COUT / 32;
+    std::vector<float> f((size_t)KT * NU * NMT * 64 * 4);
+    for (int tap = 0; tap < KT; ++tap)
+        for (int u = 0; u < NU; ++u)
+            for (int mt = 0; mt < NMT; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = 32 * mt + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + i;
+                        f[((((size_t)tap * NU + u) * NMT + mt) * 64 + lane) * 4 + i] = W[((size_t)co * CIN + ci) * KT + tap];
+                    }
+    return f;
+}
+// D-fragment order of a per-cout vector: [(mt*2+q)*16 + r] = v[32mt + (r&3) + 8(r>>2) + 4q]
+std::vector<float> dfrag32(const float* v, int COUT)
+{
+    std::vector<float> f(COUT);
+    for (int mt = 0; mt < COUT / 32; ++mt)
+        for (int q = 0; q < 2; ++q)
+            for (int r = 0; r < 16; ++r) f[(mt * 2 + q) * 16 + r] = v[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q];
+    return f;
+}
+// 16x16x4 A-fragments for Cin = Cout = 16: [tap][lane][i] = W[cout = lane&15][cin = 4(lane>>4) + i][tap]
+std::vector<float> frag16(const float* W, int KT)
+{
+    std::vector<float> f((size_t)KT * 64 * 4);
+    for (int tap = 0; tap < KT; ++tap)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 4; ++i) f[((size_t)tap * 64 + lane) * 4 + i] = W[((size_t)(lane & 15) * 16 + 4 * (lane >> 4) + i) * KT + tap];
+    return f;
+}
+// first conv: [(kd*3+kh)][lane] = W[cout = lane&15][0][kd][kh][kw = lane>>4] (0 for the pad slot)
+std::vector<float> frag_first(const float* W)
+{
+    std::vector<float> f(9 * 64);
+    for (int t = 0; t < 9; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int kw = lane >> 4;
+            f[t * 64 + lane] = kw < 3 ? W[(lane & 15) * 27 + t * 3 + kw] : 0.0f;
+        }
+    return f;
+}
+
+int upload(vqhip_codec* c, const char* name, const std::vector<float>& v)
+{
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, v.size() * sizeof(float)));
+    HIPCHK(c, hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->dw[name] = d;
+    return VQHIP_OK;
+}
+int upload(vqhip_codec* c, const char* name, const PackTensor* t)
+{
+    return upload(c, name, std::vector<float>(t->data, t->data + t->count));
+}
+
+int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
+{
+    std::string err;
+#define NEED(var, name, ...)                                  \
+    const PackTensor* var = need(pk, name, {__VA_ARGS__}, err); \
+    if (!var) return fail(c, VQHIP_ERR_MODEL, err);
+    NEED(e0w, "encoder.pre.0.weight", 16, 1, 3, 3, 3) NEED(e0b, "encoder.pre.0.bias", 16)
+    NEED(eg0w, "encoder.pre.1.weight", 16) NEED(eg0b, "encoder.pre.1.bias", 16)
+    NEED(r16g1w, "encoder.pre.3.gn1.weight", 16) NEED(r16g1b, "encoder.pre.3.gn1.bias", 16)
+    NEED(r16c1w, "encoder.pre.3.conv1.weight", 16, 16, 3, 3, 3) NEED(r16c1b, "encoder.pre.3.conv1.bias", 16)
+    NEED(r16g2w, "encoder.pre.3.gn2.weight", 16) NEED(r16g2b, "encoder.pre.3.gn2.bias", 16)
+    NEED(r16c2w, "encoder.pre.3.conv2.weight", 16, 16, 3, 3, 3) NEED(r16c2b, "encoder.pre.3.conv2.bias", 16)
+    NEED(edw, "encoder.down.weight", 32, 16, 4, 4, 4) NEED(edb, "encoder.down.bias", 32)
+    NEED(r32g1w, "encoder.res_stack.0.gn1.weight", 32) NEED(r32g1b, "encoder.res_stack.0.gn1.bias", 32)
+    NEED(r32c1w, "encoder.res_stack.0.conv1.weight", 32, 32, 3, 3, 3) NEED(r32c1b, "encoder.res_stack.0.conv1.bias", 32)
+    NEED(r32g2w, "encoder.res_stack.0.gn2.weight", 32) NEED(r32g2b, "encoder.res_stack.0.gn2.bias", 32)
+    NEED(r32c2w, "encoder.res_stack.0.conv2.weight", 32, 32, 3, 3, 3) NEED(r32c2b, "encoder.res_stack.0.conv2.bias", 32)
+    NEED(efc0, "encoder.attn.fc.0.weight", 8, 32) NEED(efc2, "encoder.attn.fc.2.weight", 32, 8)
+    NEED(epw, "encoder.proj.weight", 128, 32, 1, 1, 1) NEED(epb, "encoder.proj.bias", 128)
+    NEED(dsw, "decoder.stem.0.weight", 64, 128, 3, 3, 3) NEED(dsb, "decoder.stem.0.bias", 64)
+    NEED(dg0w, "decoder.stem.1.weight", 64) NEED(dg0b, "decoder.stem.1.bias", 64)
+    NEED(r64g1w, "decoder.res_stack.0.gn1.weight", 64) NEED(r64g1b, "decoder.res_stack.0.gn1.bias", 64)
+    NEED(r64c1w, "decoder.res_stack.0.conv1.weight", 64, 64, 3, 3, 3) NEED(r64c1b, "decoder.res_stack.0.conv1.bias", 64)
+    NEED(r64g2w, "decoder.res_stack.0.gn2.weight", 64) NEED(r64g2b, "decoder.res_stack.0.gn2.bias", 64)
+    NEED(r64c2w, "decoder.res_stack.0.conv2.weight", 64, 64, 3, 3, 3) NEED(r64c2b, "decoder.res_stack.0.conv2.bias", 64)
+    NEED(dfc0, "decoder.attn.fc.0.weight", 16, 64) NEED(dfc2, "decoder.attn.fc.2.weight", 64, 16)
+    NEED(duw, "decoder.up_conv.weight", 256, 64, 3, 3, 3) NEED(dub, "decoder.up_conv.bias", 256)
+    NEED(dfw, "decoder.final.weight", 1, 32, 3, 3, 3) NEED(dfb, "decoder.final.bias", 1)
+    NEED(cb, "quantizer.embedding", 256, 128)
+#undef NEED
+    int rc;
+#define UP(...)                                 \
+    if ((rc = upload(c, __VA_ARGS__)) != VQHIP_OK) return rc;
+    UP("e0.w", frag_first(e0w->data)) UP("e0.b", e0b) UP("eg0.w", eg0w) UP("eg0.b", eg0b)
+    UP("r16g1.w", r16g1w) UP("r16g1.b", r16g1b) UP("r16c1.w", frag16(r16c1w->data, 27)) UP("r16c1.b", r16c1b)
+    UP("r16g2.w", r16g2w) UP("r16g2.b", r16g2b) UP("r16c2.w", frag16(r16c2w->data, 27)) UP("r16c2.b", r16c2b)
+    UP("ed.w", frag32(edw->data, 32, 16, 64)) UP("ed.b", dfrag32(edb->data, 32))
+    UP("r32g1.w", r32g1w) UP("r32g1.b", r32g1b) UP("r32c1.w", frag32(r32c1w->data, 32, 32, 27)) UP("r32c1.b", dfrag32(r32c1b->data, 32))
+    UP("r32g2.w", r32g2w) UP("r32g2.b", r32g2b) UP("r32c2.w", frag32(r32c2w->data, 32, 32, 27)) UP("r32c2.b", dfrag32(r32c2b->data, 32))
+    UP("efc0", efc0) UP("efc2", efc2) UP("ep.w", frag32(epw->data, 128, 32, 1)) UP("ep.b", dfrag32(epb->data, 128))
+    UP("ds.w", frag32(dsw->data, 64, 128, 27)) UP("ds.b", dfrag32(dsb->data, 64)) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
+    UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
+    UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
+    UP("dfc0", dfc0) UP("dfc2", dfc2) UP("du.w", frag32(duw->data, 256, 64, 27)) UP("du.b", dfrag32(dub->data, 256))
+    {
+        std::vector<float> wf(27 * 32);  // [tap][cin]
+        for (int t = 0; t < 27; ++t)
+            for (int ci = 0; ci < 32; ++ci) wf[t * 32 + ci] = dfw->data[ci * 27 + t];
+        UP("df.w", wf)
+        c->e_final_bias = dfb->data[0];
+    }
+    UP("cb", cb) UP("cb.frag", frag32(cb->data, 256, 128, 1))
+    {
+        // ||e_k||^2: fmaf chain over ascending c (arithmetic contract, oracle vqo_code_norms)
+        std::vector<float> ee(256);
+        for (int k = 0; k < 256; ++k) {
+            float s = 0.0f;
+            for (int ch = 0; ch < 128; ++ch) s = __builtin_fmaf(cb->data[k * 128 + ch], cb->data[k * 128 + ch], s);
+            ee[k] = s;
+        }
+        UP("cb.ee", dfrag32(ee.data(), 256))
+    }
+#undef UP
+    return VQHIP_OK;
+}
+
+// ---------------- workspace ----------------
+struct ActSpec {
+    const char* name;
+    int C, NP;  // floats per leaf = C*NP ; C==0 -> per-leaf scalars, NP = count
+};
+const ActSpec kActs[] = {
+    {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
+    {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},    {"e_z", 128, 64},   {"d_q", 128, 64},
+    {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},   {"d_ps", 32, 512},
+    {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64},
+};
+
+int ensure_workspace(vqhip_codec* c, int64_t n_leaves, bool want_zdbg)
+{
+    (void)want_zdbg;
+    const int64_t tiles = (n_leaves + 31) / 32;
+    if (tiles <= c->ws_tiles) return VQHIP_OK;
+    if (c->ws) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_tiles = 0;
+    }
+    size_t total = 0;
+    for (const ActSpec& a : kActs) {
+        const size_t per_leaf = (a.C ? (size_t)a.C * a.NP : (size_t)a.NP) * sizeof(float);
+        total += ((per_leaf * 32 * tiles) + 255) / 256 * 256;
+    }
+    hipError_t e = hipMalloc(&c->ws, total);
+    if (e != hipSuccess) return fail(c, VQHIP_ERR_NOMEM, std::string("workspace hipMalloc failed: ") + hipGetErrorString(e));
+    c->ws_bytes = total;
+    size_t off = 0;
+    for (const ActSpec& a : kActs) {
+        const size_t per_leaf = (a.C ? (size_t)a.C * a.NP : (size_t)a.NP) * sizeof(float);
+        c->act[a.name] = reinterpret_cast<float*>(c->ws + off);
+        c->act_shape[a.name] = {a.C, a.NP};
+        off += ((per_leaf * 32 * tiles) + 255) / 256 * 256;
+    }
+    c->ws_tiles = tiles;
+    return VQHIP_OK;
+}
+
+// ---------------- launches ----------------
+struct Launcher {
+    vqhip_codec* c;
+    hipStream_t s;
+    int64_t leaves;
+    int rc = VQHIP_OK;
+    template <typename F>
+    void run(const char* name, F&& f)
+    {
+        if (rc != VQHIP_OK) return;
+        KernelTimer t;
+        if (c->profiling) {
+            t.name = name;
+            t.leaves = leaves;
+            hipEventCreate(&t.start);
+            hipEventCreate(&t.stop);
+            hipEventRecord(t.start, s);
+        }
+        f();
+        if (c->profiling) {
+            hipEventRecord(t.stop, s);
+            c->timers.push_back(t);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            c->err = std::string("launch ") + name + ": " + hipGetErrorString(e);
+            rc = VQHIP_ERR_DEVICE;
+        }
+    }
+};
+
+template <typename K>
+int set_lds(vqhip_codec* c, K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return VQHIP_OK;
+}
+
+// kernel instantiations -------------------------------------------------------------------
+//                         CIN COUT SI SO KS ST PD NW STREAM INMODE GIN RESID GOUT CSUM  PIXSHUF
+constexpr auto k_enc_down = conv_mfma32_k<16, 32, 8, 4, 4, 2, 1, 8, false, 0, 0, false, 8, false, false>;
+constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 4, 4, 3, 1, 1, 8, false, 1, 8, false, 8, false, false>;
+constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 4, 4, 3, 1, 1, 8, false, 1, 8, true, 0, true, false>;
+constexpr auto k_dec_stem = conv_mfma32_k<128, 64, 4, 4, 3, 1, 1, 4, true, 0, 0, false, 8, false, false>;
+constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 4, 4, 3, 1, 1, 4, true, 1, 8, false, 8, false, false>;
+constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 4, 4, 3, 1, 1, 4, true, 1, 8, true, 0, true, false>;
+constexpr auto k_dec_up = conv_mfma32_k<64, 256, 4, 4, 3, 1, 1, 4, true, 2, 0, false, 0, false, true>;
+constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB
+constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB
+constexpr size_t LDS_DEC_STEM = (size_t)(16 * 2 * 64) * 16;       // 32 KB
+constexpr size_t LDS_DEC_R64 = (size_t)(8 * 2 * 64) * 16;         // 16 KB
+constexpr size_t LDS_DEC_UP = (size_t)(8 * 8 * 64) * 16;          // 64 KB
+constexpr size_t LDS_PROJ_VQ = (size_t)(16 * 8 * 64 + 4 * 4 * 64) * 16;  // 144 KB
+
+int init_kernel_attrs(vqhip_codec* c)
+{
+    int rc;
+    if ((rc = set_lds(c, k_enc_down, LDS_ENC_DOWN))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
+    if ((rc = set_lds(c, proj_vq_k<8>, LDS_PROJ_VQ))) return rc;
+    return VQHIP_OK;
+}
+
+int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, hipStream_t s, bool zdbg)
+{
+    int rc = ensure_workspace(c, n, zdbg);
+    if (rc) return rc;
+    const int nt = (int)((n + 31) / 32);
+    auto& a = c->act;
+    auto& w = c->dw;
+    Launcher L{c, s, n};
+    const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
+
+    L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt), dim3(256), 0, s, d_leaves, a["xt"], n); });
+    {
+        ConvArgs A{};
+        A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
+        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        L.run("enc_conv_first", [&] { hipLaunchKernelGGL(conv_first_k, dim3(g4), dim3(256), 0, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_y1"], A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
+        A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"], A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
+        L.run("enc_gn_relu_stats", [&] { hipLaunchKernelGGL((gn_relu_stats_k<16, 512, 4>), dim3(g4), dim3(256), 0, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
+        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
+        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<false, true>), dim3(g4), dim3(256), 0, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
+        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
+        L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<true, false>), dim3(g4), dim3(256), 0, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"];
+        A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
+        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down, dim3(g8), dim3(512), LDS_ENC_DOWN, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
+        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
+        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1, dim3(g8), dim3(512), LDS_ENC_R32, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
+        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
+        A.out_csum = a["csum"], A.n_tiles = nt;
+        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A); });
+    }
+    {
+        VqArgs A{};
+        A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+        A.wproj = w["ep.w"], A.bproj = w["ep.b"], A.efrag = w["cb.frag"], A.ee_frag = w["cb.ee"];
+        A.idx = d_idx, A.z_dbg = zdbg ? a["e_z"] : nullptr, A.n_leaves = n, A.n_tiles = nt;
+        L.run("enc_proj_vq", [&] { hipLaunchKernelGGL(proj_vq_k<8>, dim3(g8), dim3(512), LDS_PROJ_VQ, s, A); });
+    }
+    return L.rc;
+}
+
+int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, hipStream_t s)
+{
+    int rc = ensure_workspace(c, n, false);
+    if (rc) return rc;
+    const int nt = (int)((n + 31) / 32);
+    auto& a = c->act;
+    auto& w = c->dw;
+    Launcher L{c, s, n};
+    const int g4 = (nt + 3) / 4;
+
+    L.run("gather_codes", [&] { hipLaunchKernelGGL(gather_codes_k, dim3(nt * 16), dim3(256), 0, s, d_idx, w["cb"], a["d_q"], n, nt); });
+    {
+        ConvArgs A{};
+        A.in = a["d_q"], A.out = a["d_ystem"], A.wfrag = w["ds.w"], A.bias_frag = w["ds.b"];
+        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        L.run("dec_stem", [&] { hipLaunchKernelGGL(k_dec_stem, dim3(g4), dim3(256), LDS_DEC_STEM, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
+        A.in_gamma = w["dg0.w"], A.in_beta = w["dg0.b"], A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
+        L.run("dec_gn_relu_stats", [&] { hipLaunchKernelGGL((gn_relu_stats_k<64, 64, 8>), dim3(g4), dim3(256), 0, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
+        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"];
+        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        L.run("dec_res64_conv1", [&] { hipLaunchKernelGGL(k_dec_r64c1, dim3(g4), dim3(256), LDS_DEC_R64, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w"], A.bias_frag = w["r64c2.b"], A.skip = a["d_d2"];
+        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
+        A.out_csum = a["csum"], A.n_tiles = nt;
+        L.run("dec_res64_conv2", [&] { hipLaunchKernelGGL(k_dec_r64c2, dim3(g4), dim3(256), LDS_DEC_R64, s, A); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["d_x6"], A.out = a["d_ps"], A.wfrag = w["du.w"], A.bias_frag = w["du.b"];
+        A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt;
+        L.run("dec_up_conv", [&] { hipLaunchKernelGGL(k_dec_up, dim3(g4), dim3(256), LDS_DEC_UP, s, A); });
+    }
+    L.run("dec_final", [&] {
+        hipLaunchKernelGGL(final_conv_k, dim3((nt + 7) / 8), dim3(256), 0, s, a["d_ps"], w["df.w"], c->e_final_bias, d_out, n, nt);
+    });
+    return L.rc;
+}
+
+int ensure_io(vqhip_codec* c, int64_t n)
+{
+    if (n <= c->dev_io_leaves) return VQHIP_OK;
+    if (c->dev_leaves) hipFree(c->dev_leaves);
+    if (c->dev_idx) hipFree(c->dev_idx);
+    if (c->pin_in) hipHostFree(c->pin_in);
+    if (c->pin_out) hipHostFree(c->pin_out);
+    c->dev_leaves = nullptr, c->dev_idx = nullptr, c->pin_in = nullptr, c->pin_out = nullptr, c->dev_io_leaves = 0;
+    HIPCHK(c, hipMalloc(&c->dev_leaves, (size_t)n * 512 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->dev_idx, (size_t)n * 64));
+    HIPCHK(c, hipHostMalloc(&c->pin_in, (size_t)n * 512 * sizeof(float), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(&c->pin_out, (size_t)n * 512 * sizeof(float), hipHostMallocDefault));
+    c->dev_io_leaves = n;
+    return VQHIP_OK;
+}
+
+}  // namespace
+
+// =============================== C ABI ===============================
+extern "C" {
+
+const char* vqhip_version(void) { return "vqvdb-hip 0.1 (gfx950)"; }
+
+const char* vqhip_last_error(const vqhip_codec* codec) { return codec ? codec->err.c_str() : g_create_error.c_str(); }
+
+int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size, int device_id, vqhip_codec** out)
+{
+    if (!out) return fail(nullptr, VQHIP_ERR_INVALID, "vqhip_create: out is NULL");
+    *out = nullptr;
+    std::vector<unsigned char> file;
+    const unsigned char* p = static_cast<const unsigned char*>(pack_bytes);
+    size_t n = pack_size;
+    if (pack_path) {
+        std::ifstream f(pack_path, std::ios::binary);
+        if (!f) return fail(nullptr, VQHIP_ERR_MODEL, std::string("Model file not found at path: ") + pack_path);
+        file.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        p = file.data();
+        n = file.size();
+    }
+    if (!p || !n) return fail(nullptr, VQHIP_ERR_MODEL, "vqhip_create: no weight pack given (embedded model absent from this build)");
+    std::map<std::string, PackTensor> pk;
+    std::string err;
+    if (!parse_pack(p, n, pk, err)) return fail(nullptr, VQHIP_ERR_MODEL, err);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, VQHIP_ERR_DEVICE, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, VQHIP_ERR_INVALID, "vqhip_create: device_id out of range");
+    vqhip_codec* c = new vqhip_codec();
+    c->device = device_id;
+    auto bail = [&](int rc) {
+        g_create_error = c->err;
+        vqhip_destroy(c);
+        return rc;
+    };
+    if (hipSetDevice(device_id) != hipSuccess) {
+        c->err = "hipSetDevice failed";
+        return bail(VQHIP_ERR_DEVICE);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        c->err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return bail(VQHIP_ERR_DEVICE);
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->err = "hipStreamCreate failed";
+        return bail(VQHIP_ERR_DEVICE);
+    }
+    int rc = load_weights(c, pk);
+    if (rc) return bail(rc);
+    if ((rc = init_kernel_attrs(c))) return bail(rc);
+    *out = c;
+    return VQHIP_OK;
+}
+
+void vqhip_destroy(vqhip_codec* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& kv : c->dw) hipFree(kv.second);
+    if (c->ws) hipFree(c->ws);
+    if (c->dev_leaves) hipFree(c->dev_leaves);
+    if (c->dev_idx) hipFree(c->dev_idx);
+    if (c->pin_in) hipHostFree(c->pin_in);
+    if (c->pin_out) hipHostFree(c->pin_out);
+    for (auto& t : c->timers) {
+        hipEventDestroy(t.start);
+        hipEventDestroy(t.stop);
+    }
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vqhip_latent_shape(const vqhip_codec* c, int64_t out[3])
+{
+    if (!c || !out) return VQHIP_ERR_INVALID;
+    out[0] = out[1] = out[2] = 4;  // 8^3 leaf through the k4/s2 down-conv (weights validated at create)
+    return VQHIP_OK;
+}
+
+int vqhip_set_chunk_leaves(vqhip_codec* c, int64_t chunk)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (chunk < 32 || chunk > (1 << 22)) return fail(c, VQHIP_ERR_INVALID, "chunk_leaves must be in [32, 4194304]");
+    c->chunk = (chunk + 31) / 32 * 32;
+    return VQHIP_OK;
+}
+
+int vqhip_encode_device(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, void* stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!d_leaves || !d_idx || n < 1) return fail(c, VQHIP_ERR_INVALID, "encode: null pointer or n_leaves < 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    for (int64_t o = 0; o < n; o += c->chunk) {
+        const int64_t m = std::min(c->chunk, n - o);
+        int rc = encode_chunk(c, d_leaves + o * 512, m, d_idx + o * 64, s, c->debug);
+        if (rc) return rc;
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_decode_device(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, void* stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!d_idx || !d_out || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode: null pointer or n_leaves < 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    for (int64_t o = 0; o < n; o += c->chunk) {
+        const int64_t m = std::min(c->chunk, n - o);
+        int rc = decode_chunk(c, d_idx + o * 64, m, d_out + o * 512, s);
+        if (rc) return rc;
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_encode(vqhip_codec* c, const float* leaves, int64_t n, uint8_t* indices)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!leaves || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "encode: null pointer or n_leaves < 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t step = std::min(c->chunk, n);
+    int rc = ensure_io(c, step);
+    if (rc) return rc;
+    for (int64_t o = 0; o < n; o += step) {
+        const int64_t m = std::min(step, n - o);
+        std::memcpy(c->pin_in, leaves + o * 512, (size_t)m * 512 * sizeof(float));
+        HIPCHK(c, hipMemcpyAsync(c->dev_leaves, c->pin_in, (size_t)m * 512 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        rc = encode_chunk(c, c->dev_leaves, m, c->dev_idx, c->stream, c->debug);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->pin_out, c->dev_idx, (size_t)m * 64, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(indices + o * 64, c->pin_out, (size_t)m * 64);
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_decode(vqhip_codec* c, const uint8_t* indices, int64_t n, float* leaves)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!leaves || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode: null pointer or n_leaves < 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t step = std::min(c->chunk, n);
+    int rc = ensure_io(c, step);
+    if (rc) return rc;
+    for (int64_t o = 0; o < n; o += step) {
+        const int64_t m = std::min(step, n - o);
+        std::memcpy(c->pin_in, indices + o * 64, (size_t)m * 64);
+        HIPCHK(c, hipMemcpyAsync(c->dev_idx, c->pin_in, (size_t)m * 64, hipMemcpyHostToDevice, c->stream));
+        rc = decode_chunk(c, c->dev_idx, m, c->dev_leaves, c->stream);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->pin_out, c->dev_leaves, (size_t)m * 512 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(leaves + o * 512, c->pin_out, (size_t)m * 512 * sizeof(float));
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_debug_enable(vqhip_codec* c, int enable)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    c->debug = enable != 0;
+    return VQHIP_OK;
+}
+
+int vqhip_profile_enable(vqhip_codec* c, int enable)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    c->profiling = enable != 0;
+    return VQHIP_OK;
+}
+
+int vqhip_profile_read(vqhip_codec* c, vqhip_kernel_stat* stats, int cap, int* count)
+{
+    if (!c || !count) return VQHIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<std::string> order;
+    std::map<std::string, vqhip_kernel_stat> agg;
+    for (auto& t : c->timers) {
+        HIPCHK(c, hipEventSynchronize(t.stop));
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, t.start, t.stop));
+        auto it = agg.find(t.name);
+        if (it == agg.end()) {
+            vqhip_kernel_stat s{};
+            std::snprintf(s.name, sizeof(s.name), "%s", t.name.c_str());
+            auto ki = kernel_info().find(t.name);
+            if (ki != kernel_info().end()) s.flops_per_leaf = ki->second.flops, s.eff_flops_per_leaf = ki->second.eff_flops;
+            it = agg.emplace(t.name, s).first;
+            order.push_back(t.name);
+        }
+        it->second.launches += 1;
+        it->second.total_ms += ms;
+        it->second.leaves += t.leaves;
+        hipEventDestroy(t.start);
+        hipEventDestroy(t.stop);
+    }
+    c->timers.clear();
+    *count = (int)order.size();
+    for (int i = 0; i < (int)order.size() && i < cap && stats; ++i) stats[i] = agg[order[i]];
+    return VQHIP_OK;
+}
+
+int vqhip_debug_fetch(vqhip_codec* c, const char* name, int64_t n, float* out)
+{
+    if (!c || !name || !out || n < 1) return VQHIP_ERR_INVALID;
+    auto it = c->act.find(name);
+    if (it == c->act.end()) return fail(c, VQHIP_ERR_INVALID, std::string("debug_fetch: unknown activation '") + name + "'");
+    const int C = c->act_shape[name].first, NP = c->act_shape[name].second;
+    if (C < 4 || n > c->ws_tiles * 32) return fail(c, VQHIP_ERR_INVALID, "debug_fetch: not an L4 activation or n too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t tiles = (n + 31) / 32;
+    std::vector<float> raw((size_t)tiles * 32 * C * NP);
+    HIPCHK(c, hipMemcpy(raw.data(), it->second, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t l = 0; l < n; ++l)
+        for (int ch = 0; ch < C; ++ch)
+            for (int p = 0; p < NP; ++p)
+                out[((size_t)l * C + ch) * NP + p] = raw[((((size_t)(l / 32) * NP + p) * (C / 4) + ch / 4) * 32 + (l % 32)) * 4 + ch % 4];
+    return VQHIP_OK;
+}
+
+int vqhip_selftest_mfma(vqhip_codec* c, int64_t* mismatches)
+{
+    if (!c || !mismatches) return VQHIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ks = 24;
+    std::vector<float> h((size_t)(32 * 2 * ks) * 2 + (size_t)(16 * 4 * ks) * 2);
+    uint32_t x = 12345u;
+    for (auto& v : h) {
+        x = x * 1664525u + 1013904223u;
+        v = ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 22)) * (1.0f + (float)(x & 7));
+    }
+    float* d = nullptr;
+    unsigned long long* dm = nullptr;
+    HIPCHK(c, hipMalloc(&d, h.size() * sizeof(float)));
+    HIPCHK(c, hipMalloc(&dm, 2 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(dm, 0, 2 * sizeof(unsigned long long)));
+    const float* a32 = d;
+    const float* b32 = a32 + 32 * 2 * ks;
+    const float* a16 = b32 + 32 * 2 * ks;
+    const float* b16 = a16 + 16 * 4 * ks;
+    hipLaunchKernelGGL(mfma_probe_k, dim3(1), dim3(64), 0, c->stream, a32, b32, a16, b16, ks, dm);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long hm[2] = {0, 0};
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(hm, dm, sizeof(hm), hipMemcpyDeviceToHost));
+    hipFree(d);
+    hipFree(dm);
+    mismatches[0] = (int64_t)hm[0];
+    mismatches[1] = (int64_t)hm[1];
+    return VQHIP_OK;
+}
+
+}  // extern "C"
