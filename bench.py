@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Throughput bench of the VQ-VAE leaf hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one 65,536-leaf batch per GPU, inputs resident in HBM
+(config 2 of BASELINE.json: "1xMI355X, 1M synthetic leaves, fp32 encoder+quantizer", i.e. 16
+steps of 64k leaves).  `value` is encode+quantize leaves/s over all ranks; the decode leg is
+timed the same way and reported under "decode".  Leaves shard across ranks with no data-path
+collective (weak scaling: per-GPU work is fixed).  PyTorch is used only for device memory,
+streams/events and the torch.distributed barrier.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vqvdb_amd import synth, weightpack  # noqa: E402
+from vqvdb_amd.codec import HipCodec  # noqa: E402
+
+BATCH = 65536
+ENC_FLOP = 30_589_952      # nominal dense FLOP / leaf
+DEC_FLOP = 114_135_040
+ENC_FLOP_EFF = 22_869_760  # zero-padding taps excluded (informational)
+DEC_FLOP_EFF = 66_221_568
+PEAK_TF = 157.3            # fp32 MFMA dense peak per MI355X (MI355X_MICROARCH.md)
+
+
+def timed(fn, steps, dist, device):
+    if dist:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        fn(s)
+    torch.cuda.synchronize(device)
+    if dist:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def profile_pass(codec, fn, steps, device, flop_key):
+    """Per-kernel averages from HIP events on the launch stream (library hook)."""
+    codec.profile_enable(True)
+    for s in range(steps):
+        fn(s)
+    torch.cuda.synchronize(device)
+    stats = codec.profile_read()
+    codec.profile_enable(False)
+    out = []
+    for st in stats:
+        avg_ms = st["total_ms"] / max(st["launches"], 1)
+        leaves = st["leaves"] / max(st["launches"], 1)
+        out.append(dict(kernel=st["name"], avg_ms=round(avg_ms, 4), launches=st["launches"],
+                        tflops=round(st[flop_key] * leaves / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0,
+                        tflops_effective=round(st["eff_flops_per_leaf"] * leaves / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0))
+    return out
+
+
+def roofline_of(kernels, total_flop_per_leaf, leaves_per_s_per_gpu):
+    dom = max(kernels, key=lambda k: k["avg_ms"])
+    return {
+        "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_TF, "unit": "TFLOP/s",
+        "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": None,
+        "achieved_effective": dom["tflops_effective"], "avg_launch_ms": dom["avg_ms"],
+        "whole_path_frac": round(leaves_per_s_per_gpu * total_flop_per_leaf / (PEAK_TF * 1e12), 4),
+        "note": "achieved = nominal dense FLOP per leaf of this kernel (padding taps counted) x 65536 leaves / avg launch time; "
+                "the kernel skips zero-padding taps, so nominal can exceed the MFMA peak; *_effective excludes them",
+    }
+
+
+def cpu_baseline():
+    """CPU oracle (the repo's C restatement of the reference path, kind 'port') on a bounded sample."""
+    from oracle.oracle import Oracle
+    W = synth.make_weights(0)
+    orc = Oracle(W, [t[0] for t in synth.TENSORS])
+    threads = os.cpu_count() or 1
+    n = max(256, min(8192, 64 * threads))
+    leaves = synth.make_leaves(n, seed=1234)
+    orc.encode(leaves[:threads * 16], threads=threads)
+    t0 = time.perf_counter(); idx = orc.encode(leaves, threads=threads); te = time.perf_counter() - t0
+    nd = max(128, n // 4)
+    t0 = time.perf_counter(); orc.decode(idx[:nd], threads=threads); td = time.perf_counter() - t0
+    return {"value": round(n / te, 1), "unit": "leaves/s", "cores": threads, "kind": "port",
+            "sample": f"{n} uniform-random leaves encode+quantize ({te:.1f} s), {nd} leaves decode ({td:.1f} s); OpenMP over 16-leaf tiles",
+            "decode_value": round(nd / td, 1)}, (leaves, idx)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.gpus != 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    W = synth.make_weights(0)
+    codec = HipCodec(weightpack.dumps(W), device_id=local)
+    codec.set_chunk_leaves(BATCH)
+
+    # synthetic leaves, uniform [0,1) (training data is [0,1]-normalised), resident in HBM; each
+    # rank gets its own shard (different seed) -> no data-path collective.
+    nb = min(args.steps, 16)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    leaves = [torch.rand(BATCH, 512, device=device, dtype=torch.float32, generator=gen) for _ in range(nb)]
+    idx = [torch.empty(BATCH, 64, device=device, dtype=torch.uint8) for _ in range(nb)]
+    rec = torch.empty(BATCH, 512, device=device, dtype=torch.float32)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def enc(s):
+        codec.encode_device(leaves[s % nb].data_ptr(), BATCH, idx[s % nb].data_ptr(), stream)
+
+    def dec(s):
+        codec.decode_device(idx[s % nb].data_ptr(), BATCH, rec.data_ptr(), stream)
+
+    for s in range(max(args.warmup, 1)):
+        enc(s)
+    for s in range(nb):            # make sure every index buffer is populated for the decode leg
+        enc(s)
+    for s in range(max(args.warmup, 1)):
+        dec(s)
+    t_enc = timed(enc, args.steps, dist, device)
+    t_dec = timed(dec, args.steps, dist, device)
+    enc_lps = world * args.steps * BATCH / t_enc
+    dec_lps = world * args.steps * BATCH / t_dec
+
+    if rank == 0:
+        ek = profile_pass(codec, enc, min(args.steps, 4), device, "flops_per_leaf")
+        dk = profile_pass(codec, dec, min(args.steps, 4), device, "flops_per_leaf")
+        # spot parity: first 64 leaves of batch 0 vs the CPU oracle
+        parity = None
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu, _ = cpu_baseline()
+            from oracle.oracle import Oracle
+            orc = Oracle(W, [t[0] for t in synth.TENSORS])
+            h = leaves[0][:64].cpu().numpy()
+            enc(0)
+            torch.cuda.synchronize(device)
+            gi = idx[0][:64].cpu().numpy()
+            oi = orc.encode(h, threads=os.cpu_count() or 1)
+            parity = f"{int((gi == oi).all(axis=1).sum())}/64 sampled leaves index-exact vs CPU oracle"
+        out = {
+            "metric": "8^3 leaves/s encode+quantize (decode reported under 'decode')",
+            "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_enc / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1xMI355X, 1M synthetic leaves in 65536-leaf batches, fp32 encoder+quantizer, K=256 D=128",
+                       "leaves_per_step_per_gpu": BATCH, "sharding": f"leaves sharded over {world} rank(s), no collective"},
+            "roofline": roofline_of(ek, ENC_FLOP, enc_lps / world),
+            "cpu_baseline": cpu,
+            "decode": {
+                "value": round(dec_lps, 1), "unit": "leaves/s", "ms_per_step": round(t_dec / args.steps * 1e3, 4),
+                "workload": "BASELINE configs[2] kernel path: decode of 65536-leaf index batches resident in HBM",
+                "roofline": roofline_of(dk, DEC_FLOP, dec_lps / world),
+            },
+            "kernels": {"encode": ek, "decode": dk},
+            "flop_per_leaf": {"encode_nominal": ENC_FLOP, "encode_effective": ENC_FLOP_EFF, "decode_nominal": DEC_FLOP, "decode_effective": DEC_FLOP_EFF},
+            "parity_sample": parity,
+        }
+        print(json.dumps(out))
+    if dist:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""CPU-only checks of the host side: weight pack round trip, the C-ABI library loads and
+exports every symbol include/vqvdb_hip.h declares, header/ctypes agreement, and the
+no-GPU failure mode (loud error, no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from vqvdb_amd import codec as vc
+from vqvdb_amd import synth, weightpack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_weightpack_roundtrip(weights, tmp_path):
+    blob = weightpack.dumps(weights)
+    back = weightpack.loads(blob)
+    assert list(back) == [t[0] for t in synth.TENSORS]
+    for k, v in weights.items():
+        assert back[k].shape == v.shape and np.array_equal(back[k], v)
+    p = tmp_path / "model.vqw"
+    weightpack.save(p, weights)
+    assert np.array_equal(weightpack.load(p)["encoder.down.weight"], weights["encoder.down.weight"])
+    with pytest.raises(ValueError):
+        weightpack.loads(b"garbage-garbage-")
+
+
+def test_from_state_dict_drops_training_buffers(weights):
+    sd = dict(weights)
+    sd["quantizer.cluster_size"] = np.ones(256, np.float32)
+    sd["quantizer.embed_avg"] = weights["quantizer.embedding"].copy()
+    out = weightpack.from_state_dict(sd)
+    assert set(out) == set(weights)
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vqvdb_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqhip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vqvdb_amd.build import build
+    lib = ctypes.CDLL(build())
+    declared = _declared_symbols()
+    assert sorted(vc.ABI_SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in ctypes.cast(lib.vqhip_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_create_fails_loudly_without_gpu_or_pack(weights, capsys):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the failure path is covered by the -m gpu tests")
+    with pytest.raises(RuntimeError, match="no HIP device|hip"):
+        vc.HipCodec(weightpack.dumps(weights))
+    be = vc.IVQVAECodec.create(vc.CodecConfig(device=vc.CodecConfig.Device.CUDA, source=weightpack.dumps(weights)), vc.BackendType.HIP)
+    assert be is None and "Failed to create VQ-VAE backend" in capsys.readouterr().err
+    with pytest.raises(RuntimeError, match="bad magic"):
+        vc.HipCodec(b"x" * 64)
