@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 from vqvdb_amd import synth, weightpack  # noqa: E402
 from vqvdb_amd.codec import HipCodec  # noqa: E402
+from vqvdb_amd.sharding import max_over_ranks  # noqa: E402
 
 BATCH = 65536
 ENC_FLOP = 30_589_952      # nominal dense FLOP / leaf
@@ -47,11 +48,7 @@ def timed(fn, steps, dist, device):
     if dist:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    return max_over_ranks(dt, device) if dist else dt
 
 
 def profile_pass(codec, fn, steps, device, flop_key):

@@ -151,3 +151,29 @@ def test_malformed_weight_packs_fail_loudly(pack, weights):
     w["quantizer.embedding"] = w["quantizer.embedding"][:128]
     with pytest.raises(RuntimeError, match="unexpected shape"):
         HipCodec(weightpack.dumps(w))
+
+
+def test_cpp_adapter_orchestrator_roundtrip(codec, pack, tmp_path):
+    """C++ host side (HipBackend : IVQVAECodec via IVQVAECodec::create, orchestrator-style batching,
+    .vqvdb framing) gives the same bytes as the C-ABI path, for SOP-default and large batches."""
+    import subprocess
+    from vqvdb_amd.build import HARNESS
+    leaves = synth.make_leaves(1000, seed=21)
+    (tmp_path / "m.vqw").write_bytes(pack)
+    leaves.tofile(tmp_path / "in.f32")
+    want_idx = codec.encode(leaves)
+    want_rec = codec.decode(want_idx)
+    for batch in (64, 333, 4096):
+        r = subprocess.run([HARNESS, "compress", str(tmp_path / "m.vqw"), str(tmp_path / "in.f32"), str(tmp_path / "o.vqvdb"), str(batch)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        raw = (tmp_path / "o.vqvdb").read_bytes()
+        body = np.frombuffer(raw[-1000 * 76:], dtype=np.uint8).reshape(1000, 76)
+        assert np.array_equal(body[:, 12:], want_idx)
+        r = subprocess.run([HARNESS, "decompress", str(tmp_path / "m.vqw"), str(tmp_path / "o.vqvdb"), str(tmp_path / "out.f32"), str(batch)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.fromfile(tmp_path / "out.f32", dtype=np.float32).reshape(1000, 512)
+        assert np.array_equal(_bits(got), _bits(want_rec))
+    r = subprocess.run([HARNESS, "errors", str(tmp_path / "m.vqw")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

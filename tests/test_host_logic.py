@@ -61,3 +61,30 @@ def test_create_fails_loudly_without_gpu_or_pack(weights, capsys):
     assert be is None and "Failed to create VQ-VAE backend" in capsys.readouterr().err
     with pytest.raises(RuntimeError, match="bad magic"):
         vc.HipCodec(b"x" * 64)
+
+
+def test_vqvdb_stream_framing_roundtrip(tmp_path):
+    """The OpenVDB-free .vqvdb v3 reader/writer (vqvdb_amd/host/vqvdb_stream.hpp) against the byte
+    layout of SURVEY.md App. B, parsed independently here."""
+    import struct
+    import subprocess
+    from vqvdb_amd.build import build, build_harness
+    build()
+    exe = build_harness()
+    path = tmp_path / "t.vqvdb"
+    assert subprocess.run([exe, "streamtest", str(path)], capture_output=True).returncode == 0
+    raw = path.read_bytes()
+    magic, ver, ngrids, nemb, ndim = struct.unpack_from("<5sBBIB", raw, 0)
+    assert (magic, ver, ngrids, nemb, ndim) == (b"VQVDB", 3, 2, 256, 3)
+    off, total = 12, 0
+    for expect_name, expect_blocks in ((b"density", 700), (b"temperature", 300)):
+        (nl,) = struct.unpack_from("<I", raw, off); off += 4
+        assert raw[off:off + nl] == expect_name; off += nl
+        off += 64
+        assert struct.unpack_from("<3H", raw, off) == (4, 4, 4); off += 6
+        (nb,) = struct.unpack_from("<I", raw, off); off += 4
+        assert nb == expect_blocks
+        x, y, z = struct.unpack_from("<3i", raw, off)           # first chunk: origin then 64 index bytes
+        assert (x, y, z) == (8 * (total % 1024), 8 * ((total // 1024) % 1024), 0)
+        off += nb * 76; total += nb
+    assert off == len(raw) and total == 1000

@@ -38,7 +38,25 @@ def build(force: bool = False, report: bool = False) -> str:
                 for key in ("VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill", "SGPRs Spill", "LDS Size"):
                     if key in line and "remark" in line:
                         print(f"{name:110s} {line.split('remark:')[1].split('[-R')[0].strip()}")
+    build_harness(force or stale)
     return LIB
+
+
+HARNESS = os.path.join(HERE, "host", "leaf_harness")
+
+
+def build_harness(force: bool = False) -> str:
+    """C++ host side: IVQVAECodec adapter + factory + orchestrator-style harness (g++, links the C ABI)."""
+    srcs = [os.path.join(HERE, "host", f) for f in ("leaf_harness.cpp", "codec_factory.cpp")]
+    deps = srcs + [os.path.join(HERE, "host", "vqvdb_stream.hpp"), os.path.join(HERE, "host", "codec_interface.hpp"),
+                   os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip_backend.hpp")]
+    if force or not os.path.exists(HARNESS) or any(os.path.getmtime(d) > os.path.getmtime(HARNESS) for d in deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", HARNESS, *srcs, "-L" + HERE, "-lvqvdb_hip", "-Wl,-rpath,$ORIGIN/.."]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise RuntimeError("g++ failed building leaf_harness")
+    return HARNESS
 
 
 if __name__ == "__main__":

@@ -1,0 +1,202 @@
+// leaf_harness.cpp — drives the HIP backend exactly the way the reference orchestrator does,
+// without OpenVDB/TBB: IVQVAECodec::create -> per batch { pack leaves into a fresh contiguous
+// buffer -> TensorView -> encode -> writeBatch }  (VQVAECodec::compress, VQVAECodec.cpp:78-134) and
+// { nextBatch -> TensorView -> decode -> copy each 2 KiB leaf out } (::decompress, :137-208).
+// Leaves come from / go to raw float32 files so Python tests can compare with the C-ABI path.
+//
+//   leaf_harness compress   <pack> <leaves.f32> <out.vqvdb> <batch>
+//   leaf_harness decompress <pack> <in.vqvdb>   <out.f32>   <batch>
+//   leaf_harness errors     <pack>
+//   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
+#define VQVDB_HIP_STANDALONE
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+#include "../../include/vqvdb_hip_backend.hpp"
+#include "vqvdb_stream.hpp"
+
+namespace {
+constexpr size_t LEAF_VOXELS = 512;
+
+std::vector<float> readFloats(const std::string& path) {
+	std::ifstream f(path, std::ios::binary | std::ios::ate);
+	if (!f) throw std::runtime_error("cannot open " + path);
+	const size_t bytes = static_cast<size_t>(f.tellg());
+	std::vector<float> v(bytes / sizeof(float));
+	f.seekg(0);
+	f.read(reinterpret_cast<char*>(v.data()), static_cast<std::streamsize>(v.size() * sizeof(float)));
+	return v;
+}
+
+vqvdb::Coord3i originOf(size_t i) {  // synthetic leaf origins on the 8-voxel lattice
+	return {static_cast<int32_t>(8 * (i % 1024)), static_cast<int32_t>(8 * ((i / 1024) % 1024)), static_cast<int32_t>(8 * (i / 1048576))};
+}
+
+std::unique_ptr<IVQVAECodec> makeBackend(const std::string& pack) {
+	CodecConfig cfg;
+	cfg.device = CodecConfig::Device::CUDA;
+	cfg.source = std::filesystem::path(pack);
+	auto be = IVQVAECodec::create(cfg, BackendType::HIP);
+	if (!be) throw std::runtime_error("VQVAECodec: Backend cannot be null.");  // VQVAECodec.cpp:71-75
+	return be;
+}
+
+int compress(const std::string& pack, const std::string& in, const std::string& out, size_t batch) {
+	auto backend = makeBackend(pack);
+	const std::vector<float> all = readFloats(in);
+	const size_t total = all.size() / LEAF_VOXELS;
+	const auto t0 = std::chrono::high_resolution_clock::now();
+	vqvdb::StreamWriter writer(out);
+	vqvdb::GridMeta meta;
+	meta.name = "density";
+	meta.latentShape = backend->getLatentShape();
+	meta.totalBlocks = total;
+	writer.startGrid(meta);
+	for (size_t start = 0; start < total; start += batch) {
+		const size_t B = std::min(batch, total - start);
+		std::vector<float> hostData(B * LEAF_VOXELS);  // a fresh buffer per batch, like nextBatch()
+		std::vector<vqvdb::Coord3i> origins(B);
+		for (size_t i = 0; i < B; ++i) {
+			origins[i] = originOf(start + i);
+			std::memcpy(hostData.data() + i * LEAF_VOXELS, all.data() + (start + i) * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
+		}
+		TensorView view;
+		view.data = hostData.data();
+		view.shape = {static_cast<int64_t>(B), 1, 8, 8, 8};
+		view.dtype = DataType::FLOAT32;
+		const Tensor encoded = backend->encode(view);
+		if (encoded.dtype != DataType::UINT8 || encoded.shape.size() != 4 || encoded.shape[0] != static_cast<int64_t>(B))
+			throw std::runtime_error("unexpected encode result shape");
+		writer.writeBatch(encoded.getData<uint8_t>(), origins.data(), B);
+	}
+	writer.endGrid();
+	writer.close();
+	const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+	std::printf("Grid Compression Complete in %lld ms (%zu leaves, batch %zu).\n", static_cast<long long>(ms), total, batch);
+	return 0;
+}
+
+int decompress(const std::string& pack, const std::string& in, const std::string& out, size_t batch) {
+	auto backend = makeBackend(pack);
+	const auto t0 = std::chrono::high_resolution_clock::now();
+	vqvdb::StreamReader reader(in);
+	std::ofstream of(out, std::ios::binary | std::ios::trunc);
+	size_t leafNo = 0;
+	while (reader.hasNextGrid()) {
+		const vqvdb::GridMeta meta = reader.nextGrid();
+		std::vector<uint8_t> idx;
+		std::vector<vqvdb::Coord3i> origins;
+		while (reader.hasNext()) {
+			const size_t B = reader.nextBatch(batch, idx, origins);
+			if (B == 0) break;
+			TensorView view;
+			view.data = idx.data();
+			view.shape = {static_cast<int64_t>(B)};
+			view.shape.insert(view.shape.end(), meta.latentShape.begin(), meta.latentShape.end());  // verbatim from the file
+			view.dtype = DataType::UINT8;
+			const Tensor decoded = backend->decode(view);
+			if (decoded.shape.size() != 5) throw std::runtime_error("decode result is not 5-D");
+			const float* src = decoded.getData<float>();
+			for (size_t i = 0; i < B; ++i) {  // stand-in for touchLeaf + memcpy + setValuesOn
+				const vqvdb::Coord3i o = originOf(leafNo + i);
+				if (std::memcmp(&o, &origins[i], 12) != 0) throw std::runtime_error("origin mismatch in stream");
+				of.write(reinterpret_cast<const char*>(src + i * LEAF_VOXELS), LEAF_VOXELS * sizeof(float));
+			}
+			leafNo += B;
+		}
+	}
+	const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+	std::printf("Multi-Grid Decompression Complete in %lld ms (%zu leaves, batch %zu).\n", static_cast<long long>(ms), leafNo, batch);
+	return 0;
+}
+
+// .vqvdb framing round trip without any backend (CPU-only test hook): two grids, ragged batches
+int streamtest(const std::string& path) {
+	std::vector<uint8_t> idx(1000 * 64);
+	for (size_t i = 0; i < idx.size(); ++i) idx[i] = static_cast<uint8_t>((i * 2654435761u) >> 24);
+	std::vector<vqvdb::Coord3i> org(1000);
+	for (size_t i = 0; i < org.size(); ++i) org[i] = originOf(i);
+	{
+		vqvdb::StreamWriter w(path);
+		for (int g = 0; g < 2; ++g) {
+			vqvdb::GridMeta m;
+			m.name = g ? "temperature" : "density";
+			m.totalBlocks = g ? 300 : 700;
+			m.transform[0] = 0.5f + g;
+			w.startGrid(m);
+			const size_t base = g ? 700 : 0, n = m.totalBlocks;
+			for (size_t s = 0; s < n; s += 128) w.writeBatch(idx.data() + (base + s) * 64, org.data() + base + s, std::min<size_t>(128, n - s));
+			w.endGrid();
+		}
+	}
+	vqvdb::StreamReader r(path);
+	size_t seen = 0;
+	int grids = 0;
+	while (r.hasNextGrid()) {
+		const vqvdb::GridMeta m = r.nextGrid();
+		if (m.latentShape != std::vector<int64_t>{4, 4, 4} || m.numEmbeddings != 256 || m.transform[0] != 0.5f + grids) return 1;
+		if (m.name != (grids ? "temperature" : "density")) return 1;
+		std::vector<uint8_t> bi;
+		std::vector<vqvdb::Coord3i> bo;
+		while (r.hasNext()) {
+			const size_t n = r.nextBatch(97, bi, bo);
+			if (std::memcmp(bi.data(), idx.data() + seen * 64, n * 64) != 0 || std::memcmp(bo.data(), org.data() + seen, n * 12) != 0) return 1;
+			seen += n;
+		}
+		++grids;
+	}
+	std::printf("streamtest: %d grids, %zu leaves round-tripped\n", grids, seen);
+	return (grids == 2 && seen == 1000) ? 0 : 1;
+}
+
+int errors(const std::string& pack) {
+	int bad = 0;
+	auto expectThrow = [&](const char* what, auto&& fn, const char* msg) {
+		try {
+			fn();
+			std::printf("FAIL %s: no exception\n", what);
+			++bad;
+		} catch (const std::runtime_error& e) {
+			if (std::string(e.what()).find(msg) == std::string::npos) { std::printf("FAIL %s: '%s'\n", what, e.what()); ++bad; }
+		}
+	};
+	auto backend = makeBackend(pack);
+	std::vector<float> leaf(LEAF_VOXELS, 0.25f);
+	TensorView v;
+	v.data = leaf.data();
+	v.shape = {1, 1, 8, 8, 8};
+	v.dtype = DataType::UINT8;
+	expectThrow("encode dtype", [&] { backend->encode(v); }, "encode expects FLOAT32 data.");
+	v.dtype = DataType::FLOAT32;
+	expectThrow("decode dtype", [&] { backend->decode(v); }, "decode expects UINT8 data.");
+	v.shape = {1, 8, 8, 8};
+	expectThrow("encode shape", [&] { backend->encode(v); }, "encode expects shape");
+	CodecConfig cfg;
+	cfg.device = CodecConfig::Device::CUDA;
+	cfg.source = std::filesystem::path("/nonexistent/model.vqw");
+	if (IVQVAECodec::create(cfg, BackendType::HIP) != nullptr) { std::printf("FAIL create(missing pack) != nullptr\n"); ++bad; }
+	cfg.source = std::filesystem::path(pack);
+	if (IVQVAECodec::create(cfg, BackendType::ONNX) != nullptr) { std::printf("FAIL create(ONNX) != nullptr\n"); ++bad; }
+	cfg.device = CodecConfig::Device::CPU;
+	if (IVQVAECodec::create(cfg, BackendType::HIP) != nullptr) { std::printf("FAIL create(CPU) != nullptr\n"); ++bad; }
+	std::printf(bad ? "errors: %d failures\n" : "errors: all behaviours match (%d failures)\n", bad);
+	return bad ? 1 : 0;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+	try {
+		const std::string mode = argc > 1 ? argv[1] : "";
+		if (mode == "compress" && argc == 6) return compress(argv[2], argv[3], argv[4], std::stoul(argv[5]));
+		if (mode == "decompress" && argc == 6) return decompress(argv[2], argv[3], argv[4], std::stoul(argv[5]));
+		if (mode == "errors" && argc == 3) return errors(argv[2]);
+		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
+		std::fprintf(stderr, "usage: leaf_harness compress|decompress|errors ...\n");
+		return 2;
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "leaf_harness: %s\n", e.what());
+		return 1;
+	}
+}
