@@ -109,43 +109,53 @@ static void korder_p16(int* ord)
 }
 static void korder_nat(int cin, int* ord) { for (int c = 0; c < cin; ++c) ord[c] = c; }
 
-/* ---- conv3d, activations [C][S^3][LT] ---- */
+/* ---- conv3d, activations [C][S^3][LT] ----
+ * CB output channels are computed together only for instruction-level parallelism; every
+ * output element still sees exactly the accumulation order of the arithmetic contract. */
+#define CONV_BODY(CB)                                                                              \
+    for (int co = co0; co < co0 + (CB); co += (CB)) {                                              \
+        for (int od = 0; od < SO; ++od)                                                            \
+        for (int oh = 0; oh < SO; ++oh)                                                            \
+        for (int ow = 0; ow < SO; ++ow) {                                                          \
+            float acc[CB][LT];                                                                     \
+            for (int b = 0; b < (CB); ++b) for (int l = 0; l < LT; ++l) acc[b][l] = 0.0f;          \
+            for (int kd = 0; kd < K; ++kd) {                                                       \
+                const int id = od * stride - pad + kd;                                             \
+                if (id < 0 || id >= SI) continue;                                                  \
+                for (int kh = 0; kh < K; ++kh) {                                                   \
+                    const int ih = oh * stride - pad + kh;                                         \
+                    if (ih < 0 || ih >= SI) continue;                                              \
+                    for (int kw = 0; kw < K; ++kw) {                                               \
+                        const int iw = ow * stride - pad + kw;                                     \
+                        if (iw < 0 || iw >= SI) continue;                                          \
+                        const int ip = (id * SI + ih) * SI + iw;                                   \
+                        const int tap = (kd * K + kh) * K + kw;                                    \
+                        for (int cc = 0; cc < CIN; ++cc) {                                         \
+                            const int ci = kord[cc];                                               \
+                            const float* x = in + ((size_t)ci * NPI + ip) * LT;                    \
+                            for (int b = 0; b < (CB); ++b) {                                       \
+                                const float w = W[((size_t)(co + b) * CIN + ci) * K3 + tap];       \
+                                for (int l = 0; l < LT; ++l) acc[b][l] = fmaf(w, x[l], acc[b][l]); \
+                            }                                                                      \
+                        }                                                                          \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+            for (int b = 0; b < (CB); ++b) {                                                       \
+                float* o = out + ((size_t)(co + b) * NPO + (od * SO + oh) * SO + ow) * LT;         \
+                const float bb = bias[co + b];                                                     \
+                for (int l = 0; l < LT; ++l) o[l] = acc[b][l] + bb;                                \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
 static void conv3d(const float* in, float* out, const float* W, const float* bias,
                    int CIN, int COUT, int SI, int SO, int K, int stride, int pad, const int* kord)
 {
     const int NPI = SI * SI * SI, NPO = SO * SO * SO, K3 = K * K * K;
-    for (int co = 0; co < COUT; ++co) {
-        const float* Wc = W + (size_t)co * CIN * K3;
-        for (int od = 0; od < SO; ++od)
-        for (int oh = 0; oh < SO; ++oh)
-        for (int ow = 0; ow < SO; ++ow) {
-            float acc[LT];
-            for (int l = 0; l < LT; ++l) acc[l] = 0.0f;
-            for (int kd = 0; kd < K; ++kd) {
-                const int id = od * stride - pad + kd;
-                if (id < 0 || id >= SI) continue;
-                for (int kh = 0; kh < K; ++kh) {
-                    const int ih = oh * stride - pad + kh;
-                    if (ih < 0 || ih >= SI) continue;
-                    for (int kw = 0; kw < K; ++kw) {
-                        const int iw = ow * stride - pad + kw;
-                        if (iw < 0 || iw >= SI) continue;
-                        const int ip = (id * SI + ih) * SI + iw;
-                        const int tap = (kd * K + kh) * K + kw;
-                        for (int cc = 0; cc < CIN; ++cc) {
-                            const int ci = kord[cc];
-                            const float w = Wc[(size_t)ci * K3 + tap];
-                            const float* x = in + ((size_t)ci * NPI + ip) * LT;
-                            for (int l = 0; l < LT; ++l) acc[l] = fmaf(w, x[l], acc[l]);
-                        }
-                    }
-                }
-            }
-            float* o = out + ((size_t)co * NPO + (od * SO + oh) * SO + ow) * LT;
-            const float b = bias[co];
-            for (int l = 0; l < LT; ++l) o[l] = acc[l] + b;
-        }
-    }
+    int co0 = 0;
+    for (; co0 + 4 <= COUT; co0 += 4) { CONV_BODY(4) }
+    for (; co0 < COUT; co0 += 1) { CONV_BODY(1) }
 }
 
 /* first conv (Cin = 1, k3 p1) in its MFMA-shaped order: (kd,kh) valid, then kw = 0,1,2,pad */
@@ -352,19 +362,22 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
             else for (int l = 0; l < LT; ++l) zz1[l] = fmaf(v[l], v[l], zz1[l]);
         }
         for (int l = 0; l < LT; ++l) { zz[l] = zz0[l] + zz1[l]; best[l] = INFINITY; bi[l] = 0; }
-        for (int k = 0; k < 256; ++k) {
-            float dot[LT];
-            for (int l = 0; l < LT; ++l) dot[l] = 0.0f;
+        for (int k0 = 0; k0 < 256; k0 += 4) {
+            float dot[4][LT];
+            for (int b = 0; b < 4; ++b) for (int l = 0; l < LT; ++l) dot[b][l] = 0.0f;
             for (int cc = 0; cc < 128; ++cc) {
                 const int c = p8_128[cc];
-                const float e = E[k * 128 + c];
                 const float* v = z + ((size_t)c * 64 + p) * LT;
-                for (int l = 0; l < LT; ++l) dot[l] = fmaf(e, v[l], dot[l]);
+                for (int b = 0; b < 4; ++b) {
+                    const float e = E[(k0 + b) * 128 + c];
+                    for (int l = 0; l < LT; ++l) dot[b][l] = fmaf(e, v[l], dot[b][l]);
+                }
             }
-            for (int l = 0; l < LT; ++l) {
-                const float d = (zz[l] + ee[k]) - 2.0f * dot[l];
-                if (d < best[l]) { best[l] = d; bi[l] = k; }
-            }
+            for (int b = 0; b < 4; ++b)
+                for (int l = 0; l < LT; ++l) {
+                    const float d = (zz[l] + ee[k0 + b]) - 2.0f * dot[b][l];
+                    if (d < best[l]) { best[l] = d; bi[l] = k0 + b; }
+                }
         }
         for (int l = 0; l < nl; ++l) idx[(size_t)(leaf0 + l) * 64 + p] = (uint8_t)bi[l];
     }
