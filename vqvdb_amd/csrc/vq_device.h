@@ -102,12 +102,17 @@ __device__ __forceinline__ void se_hidden(const float* __restrict__ csum, const 
 #pragma unroll
     for (int j = 0; j < R; ++j) hid[j] = hid[j] > 0.0f ? hid[j] : 0.0f;
 }
+// All C gates of this lane's leaf; fc2 is addressed wave-uniformly (scalar loads), each lane
+// then selects the channels of its K-slot.  Same fmaf chain per channel as the oracle.
 template <int C>
-__device__ __forceinline__ float se_gate(const float (&hid)[C / 4], const float* __restrict__ fc2, int c)
+__device__ __forceinline__ void se_gates(const float (&hid)[C / 4], const float* __restrict__ fc2, float (&gate)[C])
 {
     constexpr int R = C / 4;
-    float a = 0.0f;
 #pragma unroll
-    for (int j = 0; j < R; ++j) a = __builtin_fmaf(fc2[c * R + j], hid[j], a);
-    return vq_sigmoid(a);
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R; ++j) a = __builtin_fmaf(fc2[c * R + j], hid[j], a);
+        gate[c] = vq_sigmoid(a);
+    }
 }

@@ -27,8 +27,27 @@ struct ConvArgs {
     float* out_mean;         // [tile][GOUT][32]
     float* out_rstd;
     float* out_csum;         // [tile][COUT][32]
+    int n_steps;             // length of the flattened (output, valid taps) schedule passed beside ConvArgs
+    int n_taps;
+    int mt_base;             // PIXSHUF only: first 32-cout tile handled by this launch (cout split over launches)
     int n_tiles;
 };
+
+// One step = one output position/row and a run of 1..KWG valid taps along kw.  x: first input
+// position (or input row base), y: first tap index (weight fragment), z: output position (or
+// output row base), w: bit0 = first step of this output, bit1 = last step, bits 8.. = number of
+// taps in the run.  Zero-padding taps simply do not appear in the table.
+struct StepEnt {
+    int ip, tap, po, flags;
+};
+
+// async global -> LDS copy of 64 float4 (1 KiB) per wave-instruction; LDS destination is the
+// wave-uniform base + lane*16 (cdna guide §5), tracked by vmcnt.
+__device__ __forceinline__ void glds16(const f32x4* gsrc_lane, f32x4* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------
 // pack: host/leaf-major leaves [n][512] -> x[tile][512][32]   (VQVAECodec.cpp:36-59 layout in)
@@ -57,8 +76,11 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
 // ------------------------------------------------------------------------------------------
 // E1: Conv3d(1->16,k3,p1) @8^3 (VQVAE_v2.py:235) + GroupNorm(4,16) statistics (:236).
 // 16x16x4 MFMA: rows = 16 couts, cols = 16 leaves, K = (kd,kh) x {kw0,kw1,kw2,pad}.
+// A wave owns a 32-leaf tile (two 16-leaf sub-tiles) and a full output row of 8 positions
+// (16 independent accumulators); steps = (output row, valid (kd,kh)), next step's 16 input
+// dwords are prefetched while the current 16 MFMAs issue.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_first_k(ConvArgs A)
+__global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __restrict__ steps)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -69,50 +91,80 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A)
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = A.wfrag[t * 64 + lane];
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
-    const float* x = A.in + (size_t)tile * 512 * 32;
-    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32;
+    const float* x = A.in + (size_t)tile * 512 * 32 + jj;
+    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+    // per-lane input column offsets of the 8 outputs of a row: iw = ow + q4 - 1 (pad slot / halo -> 0)
+    int off[8];
+    bool ok[8];
+#pragma unroll
+    for (int ow = 0; ow < 8; ++ow) {
+        const int iw = ow + q4 - 1;
+        ok[ow] = (q4 < 3) && iw >= 0 && iw < 8;
+        off[ow] = (ok[ow] ? iw : 0) * 32;
+    }
     GnAcc st[2];
     st[0].init();
     st[1].init();
-    for (int od = 0; od < 8; ++od)
-        for (int oh = 0; oh < 8; ++oh)
+    const int NS = A.n_steps;
+    int4 e = steps[0];
+    int4 en = steps[1];
+    float xn[8][2];
+#pragma unroll
+    for (int ow = 0; ow < 8; ++ow) {
+        xn[ow][0] = x[e.x * 32 + off[ow]];
+        xn[ow][1] = x[e.x * 32 + off[ow] + 16];
+    }
+    int si = 0;
+    for (int row = 0; row < 64; ++row) {
+        f32x4 acc[8][2];
+#pragma unroll
+        for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
+        bool last;
+        do {
+            float xc[8][2];
+#pragma unroll
             for (int ow = 0; ow < 8; ++ow) {
-                f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-                const int iw = ow + q4 - 1;
-                const bool okw = (q4 < 3) && iw >= 0 && iw < 8;
-                const int iwc = okw ? iw : 0;
-#pragma unroll
-                for (int kd = 0; kd < 3; ++kd) {
-                    const int id = od + kd - 1;
-                    if (id < 0 || id > 7) continue;
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        const int ih = oh + kh - 1;
-                        if (ih < 0 || ih > 7) continue;
-                        const float* xp = x + (size_t)((id * 8 + ih) * 8 + iwc) * 32 + jj;
-                        const float b0 = okw ? xp[0] : 0.0f;
-                        const float b1 = okw ? xp[16] : 0.0f;
-                        acc[0] = mfma16(w[kd * 3 + kh], b0, acc[0]);
-                        acc[1] = mfma16(w[kd * 3 + kh], b1, acc[1]);
-                    }
-                }
-                const int po = (od * 8 + oh) * 8 + ow;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    f32x4 v = acc[s] + bias4;
-                    out4[((size_t)po * 4 + q4) * 32 + 16 * s + jj] = v;
-                    st[s].add(v.x);
-                    st[s].add(v.y);
-                    st[s].add(v.z);
-                    st[s].add(v.w);
-                }
+                xc[ow][0] = ok[ow] ? xn[ow][0] : 0.0f;
+                xc[ow][1] = ok[ow] ? xn[ow][1] : 0.0f;
             }
+            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+            for (int ow = 0; ow < 8; ++ow) {  // unconditional: en is clamped to the last entry
+                xn[ow][0] = x[en.x * 32 + off[ow]];
+                xn[ow][1] = x[en.x * 32 + off[ow] + 16];
+            }
+            // e.y = kd*3+kh selects the weight register; a 9-way uniform switch keeps the index static
+            float wv = w[0];
+#pragma unroll
+            for (int t = 1; t < 9; ++t) wv = (e.y == t) ? w[t] : wv;
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) {
+                acc[ow][0] = mfma16(wv, xc[ow][0], acc[ow][0]);
+                acc[ow][1] = mfma16(wv, xc[ow][1], acc[ow][1]);
+            }
+            last = (e.w & 2) != 0;
+            e = en;
+            en = en2;
+            ++si;
+        } while (!last);
+#pragma unroll
+        for (int ow = 0; ow < 8; ++ow)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const f32x4 v = acc[ow][sb] + bias4;
+                out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;
+                st[sb].add(v.x);
+                st[sb].add(v.y);
+                st[sb].add(v.z);
+                st[sb].add(v.w);
+            }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
         float m, r;
-        gn_finish(st[s].s, st[s].q, 1.0 / 2048.0, m, r);
-        A.out_mean[((size_t)tile * 4 + q4) * 32 + 16 * s + jj] = m;
-        A.out_rstd[((size_t)tile * 4 + q4) * 32 + 16 * s + jj] = r;
+        gn_finish(st[sb].s, st[sb].q, 1.0 / 2048.0, m, r);
+        A.out_mean[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj] = m;
+        A.out_rstd[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj] = r;
     }
 }
 
@@ -199,11 +251,13 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
 // E4/E6: Conv3d(16->16,k3,p1) @8^3 inside ResidualBlock(16) (VQVAE_v2.py:190-210, :238).
 // 16x16x4 MFMA (rows 16 couts, cols 16 leaves, K = 4 channels/step, order P16); one wave owns
 // a 32-leaf tile as two 16-leaf sub-tiles and register-blocks a full row of 8 outputs so each
-// loaded input float4 feeds up to 3 taps.  Input transform relu(GroupNorm(8,16)) is applied
-// once per loaded element.  Weights (27 KB) stay resident in LDS.
+// loaded input float4 feeds up to 3 taps.  Steps = (output row, valid (kd,kh)); the next step's
+// input row (16 float4 per lane) is prefetched while the current step's ~176 MFMAs issue.
+// Input transform relu(GroupNorm(8,16)) is applied once per loaded element.  Weights (27 KB)
+// stay resident in LDS.
 // ------------------------------------------------------------------------------------------
 template <bool RESID, bool STATS>
-__global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A)
+__global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     __shared__ f32x4 wl[27 * 64];
     for (int i = threadIdx.x; i < 27 * 64; i += 256) wl[i] = ((const f32x4*)A.wfrag)[i];
@@ -215,14 +269,14 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A)
     const int jj = lane & 15, q4 = lane >> 4;
     float ia[2][4], ib[2][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = 4 * q4 + i, g = c >> 1;
-            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + 16 * s + jj];
-            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + 16 * s + jj];
-            ia[s][i] = rstd * A.in_gamma[c];
-            ib[s][i] = __builtin_fmaf(-mean, ia[s][i], A.in_beta[c]);
+            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + 16 * sb + jj];
+            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + 16 * sb + jj];
+            ia[sb][i] = rstd * A.in_gamma[c];
+            ib[sb][i] = __builtin_fmaf(-mean, ia[sb][i], A.in_beta[c]);
         }
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
@@ -230,106 +284,127 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A)
     const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
     GnAcc st[2][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        st[s][0].init();
-        st[s][1].init();
+    for (int sb = 0; sb < 2; ++sb) {
+        st[sb][0].init();
+        st[sb][1].init();
     }
-    for (int od = 0; od < 8; ++od)
-        for (int oh = 0; oh < 8; ++oh) {
-            f32x4 acc[8][2];
+    const int NS = A.n_steps;
+    int4 e = steps[0];
+    int4 en = steps[1];
+    f32x4 xn[8][2];
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) {
-                acc[ow][0] = (f32x4){0, 0, 0, 0};
-                acc[ow][1] = (f32x4){0, 0, 0, 0};
-            }
-            const int kd0 = od == 0 ? 1 : 0, kd1 = od == 7 ? 2 : 3;
-            const int kh0 = oh == 0 ? 1 : 0, kh1 = oh == 7 ? 2 : 3;
-            for (int kd = kd0; kd < kd1; ++kd)
-                for (int kh = kh0; kh < kh1; ++kh) {
-                    const int id = od + kd - 1, ih = oh + kh - 1;
-                    f32x4 xin[8][2];
+    for (int iw = 0; iw < 8; ++iw) {
+        xn[iw][0] = in4[((size_t)(e.x + iw) * 4) * 32];
+        xn[iw][1] = in4[((size_t)(e.x + iw) * 4) * 32 + 16];
+    }
+    int si = 0;
+    for (int row = 0; row < 64; ++row) {
+        f32x4 acc[8][2];
 #pragma unroll
-                    for (int iw = 0; iw < 8; ++iw)
+        for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
+        bool last;
+        do {
+            f32x4 xc[8][2];
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            f32x4 v = in4[((size_t)((id * 8 + ih) * 8 + iw) * 4) * 32 + 16 * s];
-                            v.x = fmaxf(__builtin_fmaf(v.x, ia[s][0], ib[s][0]), 0.0f);
-                            v.y = fmaxf(__builtin_fmaf(v.y, ia[s][1], ib[s][1]), 0.0f);
-                            v.z = fmaxf(__builtin_fmaf(v.z, ia[s][2], ib[s][2]), 0.0f);
-                            v.w = fmaxf(__builtin_fmaf(v.w, ia[s][3], ib[s][3]), 0.0f);
-                            xin[iw][s] = v;
-                        }
-                    const f32x4* wt = wl + (kd * 3 + kh) * 3 * 64 + lane;
-                    const f32x4 w0 = wt[0], w1 = wt[64], w2 = wt[128];
+            for (int iw = 0; iw < 8; ++iw)
 #pragma unroll
-                    for (int ow = 0; ow < 8; ++ow)
-#pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) {
-                            const int iw = ow + kw - 1;
-                            if (iw < 0 || iw > 7) continue;
-                            const f32x4 w = kw == 0 ? w0 : (kw == 1 ? w1 : w2);
-#pragma unroll
-                            for (int s = 0; s < 2; ++s) {
-                                acc[ow][s] = mfma16(w.x, xin[iw][s].x, acc[ow][s]);
-                                acc[ow][s] = mfma16(w.y, xin[iw][s].y, acc[ow][s]);
-                                acc[ow][s] = mfma16(w.z, xin[iw][s].z, acc[ow][s]);
-                                acc[ow][s] = mfma16(w.w, xin[iw][s].w, acc[ow][s]);
-                            }
-                        }
+                for (int sb = 0; sb < 2; ++sb) {
+                    f32x4 v = xn[iw][sb];
+                    v.x = fmaxf(__builtin_fmaf(v.x, ia[sb][0], ib[sb][0]), 0.0f);
+                    v.y = fmaxf(__builtin_fmaf(v.y, ia[sb][1], ib[sb][1]), 0.0f);
+                    v.z = fmaxf(__builtin_fmaf(v.z, ia[sb][2], ib[sb][2]), 0.0f);
+                    v.w = fmaxf(__builtin_fmaf(v.w, ia[sb][3], ib[sb][3]), 0.0f);
+                    xc[iw][sb] = v;
                 }
+            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
+#pragma unroll
+            for (int iw = 0; iw < 8; ++iw) {  // unconditional: en is clamped to the last entry
+                xn[iw][0] = in4[((size_t)(en.x + iw) * 4) * 32];
+                xn[iw][1] = in4[((size_t)(en.x + iw) * 4) * 32 + 16];
+            }
+            const f32x4* wt = wl + e.y * 3 * 64 + lane;   // e.y = kd*3+kh
+            const f32x4 w0 = wt[0], w1 = wt[64], w2 = wt[128];
 #pragma unroll
             for (int ow = 0; ow < 8; ++ow)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const size_t o = ((size_t)((od * 8 + oh) * 8 + ow) * 4) * 32 + 16 * s;
-                    f32x4 v = acc[ow][s] + bias4;
-                    if (RESID) {
-                        const f32x4 sk = skip4[o];
-                        const f32x4 u = v * 0.1f;
-                        v = sk + u;
-                    }
-                    out4[o] = v;
-                    if (STATS) {
-                        st[s][0].add(v.x);
-                        st[s][0].add(v.y);
-                        st[s][1].add(v.z);
-                        st[s][1].add(v.w);
-                    }
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow + kw - 1;
+                    if (iw < 0 || iw > 7) continue;
+                    const f32x4 w = kw == 0 ? w0 : (kw == 1 ? w1 : w2);
+                    // two independent accumulator chains interleaved (16x16x4: 32-cycle issue, 40-cycle dependent latency)
+                    acc[ow][0] = mfma16(w.x, xc[iw][0].x, acc[ow][0]);
+                    acc[ow][1] = mfma16(w.x, xc[iw][1].x, acc[ow][1]);
+                    acc[ow][0] = mfma16(w.y, xc[iw][0].y, acc[ow][0]);
+                    acc[ow][1] = mfma16(w.y, xc[iw][1].y, acc[ow][1]);
+                    acc[ow][0] = mfma16(w.z, xc[iw][0].z, acc[ow][0]);
+                    acc[ow][1] = mfma16(w.z, xc[iw][1].z, acc[ow][1]);
+                    acc[ow][0] = mfma16(w.w, xc[iw][0].w, acc[ow][0]);
+                    acc[ow][1] = mfma16(w.w, xc[iw][1].w, acc[ow][1]);
                 }
-        }
+            last = (e.w & 2) != 0;
+            e = en;
+            en = en2;
+            ++si;
+        } while (!last);
+#pragma unroll
+        for (int ow = 0; ow < 8; ++ow)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const size_t o = ((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb;
+                f32x4 v = acc[ow][sb] + bias4;
+                if (RESID) {
+                    const f32x4 sk = skip4[o];
+                    const f32x4 u = v * 0.1f;
+                    v = sk + u;
+                }
+                out4[o] = v;
+                if (STATS) {
+                    st[sb][0].add(v.x);
+                    st[sb][0].add(v.y);
+                    st[sb][1].add(v.z);
+                    st[sb][1].add(v.w);
+                }
+            }
+    }
     if (STATS) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 float m, r;
-                gn_finish(st[s][k].s, st[s][k].q, 1.0 / 1024.0, m, r);
-                A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * s + jj] = m;
-                A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * s + jj] = r;
+                gn_finish(st[sb][k].s, st[sb][k].q, 1.0 / 1024.0, m, r);
+                A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * sb + jj] = m;
+                A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * sb + jj] = r;
             }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Generic leaf-tile conv on the 32x32x2 fp32 MFMA: rows = 32 couts, cols = 32 leaves, K order P8.
-// One wave owns one tile and walks the NPO output positions; per (position, valid tap) it
-// reads CIN/8 float4 of activations per lane and, per 32-cout tile, one ds_read_b128 of
-// weights per 4 MFMAs.  Weights are either fully LDS-resident (STREAM=false: encoder 4^3
-// layers, <=128 KB) or re-staged per (position, tap) step, all waves of the workgroup in
-// lock-step on the same step (STREAM=true: decoder layers, 0.4-1.8 MB of weights).
+// One wave owns one tile and walks a host-built, flattened schedule of (output position, valid
+// tap) steps.  Per step it consumes CIN/8 float4 of activations per lane and, per 32-cout tile,
+// one ds_read_b128 of weights per 4 MFMAs.  Software pipeline per step:
+//     wait(prefetched B(s), W(s)) -> [barrier] -> issue B(s+1) loads (+ async global->LDS copy of
+//     W(s+1) into the other LDS buffer) -> NU*NMT*4 MFMAs on B(s) with the LDS A-fragment read
+//     one group ahead -> epilogue on the last tap of a position.
+// Weights are either fully LDS-resident (STREAM=false: encoder 4^3 layers, <=128 KB) or streamed
+// one tap per step through a double-buffered LDS window, all waves of the workgroup in lock-step
+// (STREAM=true: decoder layers, 0.4-1.8 MB of weights).
 //   INMODE 0: raw input      1: relu(GroupNorm(GIN)) on load      2: squeeze-excite gate on load
 //   RESID  : out = skip + 0.1*(acc+bias)        GOUT: GroupNorm statistics of the output
 //   CSUM   : per-channel sums of the output (feeds ChannelAttention of the next kernel)
 //   PIXSHUF: store through PixelShuffle3D(2) (VQVAE_v2.py:172-187) into a 32-channel 8^3 tensor
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int NW, bool STREAM, int INMODE, int GIN,
-          bool RESID, int GOUT, bool CSUM, bool PIXSHUF>
-__global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A)
+template <int CIN, int COUT, int NPI, int NPO, int NW, bool STREAM, int KWG, int INMODE, int GIN, bool RESID, int GOUT,
+          bool CSUM, bool PIXSHUF>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
-    constexpr int NU = CIN / 8, NMT = COUT / 32, NPI = SI * SI * SI, NPO = SO * SO * SO, KT = KS * KS * KS;
-    constexpr int WTAP = NU * NMT * 64;  // float4 per tap
+    constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
+    constexpr int WTAP = NK * 64;            // float4 per tap
+    constexpr int PIECES = WTAP / (NW * 64); // 1 KiB pieces per wave per streamed tap
+    static_assert(!STREAM || (WTAP % (NW * 64) == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, q = lane >> 5;
@@ -338,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A)
     if (!active) tile = A.n_tiles - 1;
     const f32x4* wg4 = (const f32x4*)A.wfrag;
     if (!STREAM) {
-        for (int i = threadIdx.x; i < KT * WTAP; i += NW * 64) lds[i] = wg4[i];
+        for (int i = threadIdx.x; i < A.n_taps * WTAP; i += NW * 64) lds[i] = wg4[i];
         __syncthreads();
         if (!active) return;
     }
@@ -358,12 +433,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A)
                 tb[u][i] = __builtin_fmaf(-mean, ta[u][i], A.in_beta[c]);
             }
     } else if (INMODE == 2) {
-        float hid[CIN / 4];
+        float hid[CIN / 4], gall[CIN];
         se_hidden<CIN>(A.se_csum + (size_t)tile * CIN * 32 + j, A.se_fc0, hid);
+        se_gates<CIN>(hid, A.se_fc2, gall);
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ta[u][i] = se_gate<CIN>(hid, A.se_fc2, 8 * u + 4 * q + i);
+            for (int i = 0; i < 4; ++i) ta[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
     }
 
     constexpr int NST = (GOUT > 0) ? NMT * 4 : 1;
@@ -380,108 +456,145 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A)
 
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;
     const f32x4* bf4 = (const f32x4*)A.bias_frag;
+    const int NS = A.n_steps;
 
-    for (int od = 0; od < SO; ++od)
-        for (int oh = 0; oh < SO; ++oh)
-            for (int ow = 0; ow < SO; ++ow) {
-                f32x16 acc[NMT];
+    // ---- pipeline prologue: table entries two ahead, operands one step ahead ----
+    int4 e = steps[0];
+    int4 en = steps[NS > 1 ? 1 : 0];
+    f32x4 bn[KWG][NU];
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt)
+    for (int k = 0; k < KWG; ++k) {
+        const int ipn = KWG == 1 ? e.x : min(e.x + k, NPI - 1);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-                const int kd0 = max(0, PAD - od * STRIDE), kd1 = min(KS, SI + PAD - od * STRIDE);
-                const int kh0 = max(0, PAD - oh * STRIDE), kh1 = min(KS, SI + PAD - oh * STRIDE);
-                const int kw0 = max(0, PAD - ow * STRIDE), kw1 = min(KS, SI + PAD - ow * STRIDE);
-                for (int kd = kd0; kd < kd1; ++kd)
-                    for (int kh = kh0; kh < kh1; ++kh)
-                        for (int kw = kw0; kw < kw1; ++kw) {
-                            const int id = od * STRIDE - PAD + kd, ih = oh * STRIDE - PAD + kh, iw = ow * STRIDE - PAD + kw;
-                            const int ip = (id * SI + ih) * SI + iw;
-                            const int tap = (kd * KS + kh) * KS + kw;
-                            const f32x4* wl;
-                            if (STREAM) {
-                                __syncthreads();
-                                for (int i = threadIdx.x; i < WTAP; i += NW * 64) lds[i] = wg4[(size_t)tap * WTAP + i];
-                                __syncthreads();
-                                wl = lds + lane;
-                            } else {
-                                wl = lds + (size_t)tap * WTAP + lane;
+        for (int u = 0; u < NU; ++u) bn[k][u] = in4[(size_t)ipn * (CIN / 4) * 32 + u * 64];
+    }
+    if (STREAM) {
+#pragma unroll
+        for (int pc = 0; pc < PIECES; ++pc) {
+            const int piece = wave * PIECES + pc;
+            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + piece * 64);
+        }
+    }
+    int si = 0;
+    for (int po = 0; po < NPO; ++po) {
+        f32x16 acc[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        bool last;
+        do {
+            f32x4 bc[KWG][NU];
+#pragma unroll
+            for (int k = 0; k < KWG; ++k)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) bc[k][u] = bn[k][u];  // first use: waits for this step's prefetch
+            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];   // consumed one step later
+            if (STREAM) __syncthreads();  // every wave's pieces of W(s) landed; every wave done reading W(s-1)
+            // prefetch for the next step, unconditionally (the table index is clamped, so the final
+            // iteration re-requests valid data): keeps bn/LDS-window writes free of control flow
+#pragma unroll
+            for (int k = 0; k < KWG; ++k) {
+                const int ipn = KWG == 1 ? en.x : min(en.x + k, NPI - 1);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) bn[k][u] = in4[(size_t)ipn * (CIN / 4) * 32 + u * 64];
+            }
+            if (STREAM) {
+                f32x4* dst = lds + ((si + 1) & 1) * WTAP;
+#pragma unroll
+                for (int pc = 0; pc < PIECES; ++pc) {
+                    const int piece = wave * PIECES + pc;
+                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
+                }
+            }
+#pragma unroll
+            for (int kg = 0; kg < KWG; ++kg) {
+                if (kg < (e.w >> 8)) {
+                    const f32x4* wl = (STREAM ? lds + (si & 1) * WTAP : lds + (size_t)(e.y + kg) * WTAP) + lane;
+                    f32x4 a_nx = wl[0];
+                    f32x4 b;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const int u = k / NMT, mt = k % NMT;
+                        const f32x4 a = a_nx;
+                        if (k + 1 < NK) a_nx = wl[(k + 1) * 64];  // LDS A-fragment one group ahead of its MFMAs
+                        if (mt == 0) {
+                            b = bc[kg][u];
+                            if (INMODE == 1) {
+                                b.x = fmaxf(__builtin_fmaf(b.x, ta[u][0], tb[u][0]), 0.0f);
+                                b.y = fmaxf(__builtin_fmaf(b.y, ta[u][1], tb[u][1]), 0.0f);
+                                b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
+                                b.w = fmaxf(__builtin_fmaf(b.w, ta[u][3], tb[u][3]), 0.0f);
+                            } else if (INMODE == 2) {
+                                b.x = b.x * ta[u][0];
+                                b.y = b.y * ta[u][1];
+                                b.z = b.z * ta[u][2];
+                                b.w = b.w * ta[u][3];
                             }
-                            const f32x4* bp = in4 + (size_t)ip * (CIN / 4) * 32;
-#pragma unroll
-                            for (int u = 0; u < NU; ++u) {
-                                f32x4 b = bp[u * 64];
-                                if (INMODE == 1) {
-                                    b.x = fmaxf(__builtin_fmaf(b.x, ta[u][0], tb[u][0]), 0.0f);
-                                    b.y = fmaxf(__builtin_fmaf(b.y, ta[u][1], tb[u][1]), 0.0f);
-                                    b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
-                                    b.w = fmaxf(__builtin_fmaf(b.w, ta[u][3], tb[u][3]), 0.0f);
-                                } else if (INMODE == 2) {
-                                    b.x = b.x * ta[u][0];
-                                    b.y = b.y * ta[u][1];
-                                    b.z = b.z * ta[u][2];
-                                    b.w = b.w * ta[u][3];
-                                }
-#pragma unroll
-                                for (int mt = 0; mt < NMT; ++mt) {
-                                    const f32x4 w = wl[(u * NMT + mt) * 64];
-                                    acc[mt] = mfma32(w.x, b.x, acc[mt]);
-                                    acc[mt] = mfma32(w.y, b.y, acc[mt]);
-                                    acc[mt] = mfma32(w.z, b.z, acc[mt]);
-                                    acc[mt] = mfma32(w.w, b.w, acc[mt]);
-                                }
-                            }
                         }
-                // ---- epilogue for this output position ----
-                const int po = (od * SO + oh) * SO + ow;
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bias = bf4[(mt * 2 + q) * 4 + g];
-                        f32x4 v;
-                        v.x = acc[mt][4 * g + 0] + bias.x;
-                        v.y = acc[mt][4 * g + 1] + bias.y;
-                        v.z = acc[mt][4 * g + 2] + bias.z;
-                        v.w = acc[mt][4 * g + 3] + bias.w;
-                        // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
-                        const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
-                        if (RESID) {
-                            const f32x4 sk = ((const f32x4*)A.skip)[o];
-                            const f32x4 u = v * 0.1f;
-                            v = sk + u;
-                        }
-                        if (!PIXSHUF && active) ((f32x4*)A.out)[o] = v;
-                        if (GOUT > 0) {
-                            st[mt * 4 + g].add(v.x);
-                            st[mt * 4 + g].add(v.y);
-                            st[mt * 4 + g].add(v.z);
-                            st[mt * 4 + g].add(v.w);
-                        }
-                        if (CSUM) {
-                            cs[mt][4 * g + 0] = cs[mt][4 * g + 0] + v.x;
-                            cs[mt][4 * g + 1] = cs[mt][4 * g + 1] + v.y;
-                            cs[mt][4 * g + 2] = cs[mt][4 * g + 2] + v.z;
-                            cs[mt][4 * g + 3] = cs[mt][4 * g + 3] + v.w;
-                        }
-                        if (PIXSHUF) acc[mt][4 * g + 0] = v.x, acc[mt][4 * g + 1] = v.y, acc[mt][4 * g + 2] = v.z, acc[mt][4 * g + 3] = v.w;
-                    }
-                    if (PIXSHUF && active) {
-                        // cout = 32mt + 8g + 4q + i  ->  oc = cout/8 = 4mt + g, sub = cout%8 = 4q + i
-                        // out[oc][2d+q][2h+(i>>1)][2w+(i&1)]; the 4 g's form L4 group mt of the 32-ch tensor.
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int p8 = ((2 * od + q) * 8 + 2 * oh + (i >> 1)) * 8 + 2 * ow + (i & 1);
-                            f32x4 v;
-                            v.x = acc[mt][i];
-                            v.y = acc[mt][4 + i];
-                            v.z = acc[mt][8 + i];
-                            v.w = acc[mt][12 + i];
-                            ((f32x4*)A.out)[(((size_t)tile * 512 + p8) * 8 + mt) * 32 + j] = v;
-                        }
+                        acc[mt] = mfma32(a.x, b.x, acc[mt]);
+                        acc[mt] = mfma32(a.y, b.y, acc[mt]);
+                        acc[mt] = mfma32(a.z, b.z, acc[mt]);
+                        acc[mt] = mfma32(a.w, b.w, acc[mt]);
                     }
                 }
             }
+            last = (e.w & 2) != 0;
+            e = en;
+            en = en2;
+            ++si;
+        } while (!last);
+
+        // ---- epilogue for output position po ----
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = bf4[(mt * 2 + q) * 4 + g];
+                f32x4 v;
+                v.x = acc[mt][4 * g + 0] + bias.x;
+                v.y = acc[mt][4 * g + 1] + bias.y;
+                v.z = acc[mt][4 * g + 2] + bias.z;
+                v.w = acc[mt][4 * g + 3] + bias.w;
+                // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
+                const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
+                if (RESID) {
+                    const f32x4 sk = ((const f32x4*)A.skip)[o];
+                    const f32x4 u = v * 0.1f;
+                    v = sk + u;
+                }
+                if (!PIXSHUF && active) ((f32x4*)A.out)[o] = v;
+                if (GOUT > 0) {
+                    st[mt * 4 + g].add(v.x);
+                    st[mt * 4 + g].add(v.y);
+                    st[mt * 4 + g].add(v.z);
+                    st[mt * 4 + g].add(v.w);
+                }
+                if (CSUM) {
+                    cs[mt][4 * g + 0] = cs[mt][4 * g + 0] + v.x;
+                    cs[mt][4 * g + 1] = cs[mt][4 * g + 1] + v.y;
+                    cs[mt][4 * g + 2] = cs[mt][4 * g + 2] + v.z;
+                    cs[mt][4 * g + 3] = cs[mt][4 * g + 3] + v.w;
+                }
+                if (PIXSHUF) acc[mt][4 * g + 0] = v.x, acc[mt][4 * g + 1] = v.y, acc[mt][4 * g + 2] = v.z, acc[mt][4 * g + 3] = v.w;
+            }
+            if (PIXSHUF && active) {
+                // cout = 32mt + 8g + 4q + i  ->  oc = cout/8 = 4mt + g, sub = cout%8 = 4q + i
+                // out[oc][2d+q][2h+(i>>1)][2w+(i&1)]; the 4 g's form L4 group mt of the 32-ch tensor.
+                const int od = po >> 4, oh = (po >> 2) & 3, ow = po & 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p8 = ((2 * od + q) * 8 + 2 * oh + (i >> 1)) * 8 + 2 * ow + (i & 1);
+                    f32x4 v;
+                    v.x = acc[mt][i];
+                    v.y = acc[mt][4 + i];
+                    v.z = acc[mt][8 + i];
+                    v.w = acc[mt][12 + i];
+                    ((f32x4*)A.out)[(((size_t)tile * 512 + p8) * 8 + A.mt_base + mt) * 32 + j] = v;
+                }
+            }
+        }
+    }
     if (!active) return;
     if (GOUT > 0) {
         constexpr int CPGO = COUT / (GOUT > 0 ? GOUT : 1);
@@ -554,12 +667,13 @@ __global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
     const int j = lane & 31, q = lane >> 5;
     float gate[4][4];
     {
-        float hid[8];
+        float hid[8], gall[32];
         se_hidden<32>(A.se_csum + (size_t)tile * 32 * 32 + j, A.se_fc0, hid);
+        se_gates<32>(hid, A.se_fc2, gall);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gate[u][i] = se_gate<32>(hid, A.se_fc2, 8 * u + 4 * q + i);
+            for (int i = 0; i < 4; ++i) gate[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
     }
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 8 * 32 + q * 32 + j;
     const f32x4* bp4 = (const f32x4*)A.bproj;

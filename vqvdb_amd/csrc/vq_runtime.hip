@@ -51,7 +51,7 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"dec_stem", {2.0 * 14155776, 2.0 * 14155776 * 0.578704}},
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
-        {"dec_up_conv", {2.0 * (28311552 + 2048), 2.0 * (28311552 * 0.578704 + 2048)}},
+        {"dec_up_conv", {28311552.0 + 2048, 28311552.0 * 0.578704 + 2048}},  // per launch: half of the 256 couts
         {"dec_final", {2.0 * 442368, 2.0 * 442368 * 0.7703}},
     };
     return m;
@@ -67,6 +67,7 @@ struct vqhip_codec {
 
     // device weights
     std::map<std::string, float*> dw;
+    std::map<std::string, int> nsteps;
     float e_final_bias = 0.0f;
 
     // workspace
@@ -207,6 +208,65 @@ std::vector<float> frag_first(const float* W)
     return f;
 }
 
+// Flattened (output, valid tap) schedules (StepEnt, vq_kernels.h).  Zero-padding taps never enter
+// the table; taps appear in ascending (kd,kh,kw) order per output (arithmetic contract).
+std::vector<int> steps_conv(int SI, int SO, int KS, int STRIDE, int PAD, int KWG)
+{
+    std::vector<int> t;
+    for (int od = 0; od < SO; ++od)
+        for (int oh = 0; oh < SO; ++oh)
+            for (int ow = 0; ow < SO; ++ow) {
+                const size_t first = t.size();
+                for (int kd = 0; kd < KS; ++kd)
+                    for (int kh = 0; kh < KS; ++kh) {
+                        const int id = od * STRIDE - PAD + kd, ih = oh * STRIDE - PAD + kh;
+                        if (id < 0 || id >= SI || ih < 0 || ih >= SI) continue;
+                        int run = 0;  // valid taps along kw are contiguous in input position and tap index
+                        for (int kw = 0; kw < KS; ++kw) {
+                            const int iw = ow * STRIDE - PAD + kw;
+                            if (iw < 0 || iw >= SI) continue;
+                            if (run == 0 || run == KWG) {
+                                t.insert(t.end(), {(id * SI + ih) * SI + iw, (kd * KS + kh) * KS + kw, (od * SO + oh) * SO + ow, 0});
+                                run = 0;
+                            }
+                            ++run;
+                            t[t.size() - 1] = (t[t.size() - 1] & 0xff) | (run << 8);
+                        }
+                    }
+                t[first + 3] |= 1;
+                t[t.size() - 1] |= 2;
+            }
+    return t;
+}
+// 8^3 k3 row schedule: one step = (output row (od,oh), valid (kd,kh)); ip/po are row bases (pos of w=0)
+std::vector<int> steps_rows8()
+{
+    std::vector<int> t;
+    for (int od = 0; od < 8; ++od)
+        for (int oh = 0; oh < 8; ++oh) {
+            const size_t first = t.size();
+            for (int kd = 0; kd < 3; ++kd)
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int id = od + kd - 1, ih = oh + kh - 1;
+                    if (id < 0 || id > 7 || ih < 0 || ih > 7) continue;
+                    t.insert(t.end(), {(id * 8 + ih) * 8, kd * 3 + kh, (od * 8 + oh) * 8, 1 << 8});
+                }
+            t[first + 3] |= 1;
+            t[t.size() - 1] |= 2;
+        }
+    return t;
+}
+
+int upload_i(vqhip_codec* c, const char* name, const std::vector<int>& v)
+{
+    int* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, v.size() * sizeof(int)));
+    HIPCHK(c, hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->dw[name] = reinterpret_cast<float*>(d);
+    c->nsteps[name] = (int)(v.size() / 4);
+    return VQHIP_OK;
+}
+
 int upload(vqhip_codec* c, const char* name, const std::vector<float>& v)
 {
     float* d = nullptr;
@@ -263,7 +323,8 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ds.w", frag32(dsw->data, 64, 128, 27)) UP("ds.b", dfrag32(dsb->data, 64)) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
     UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
-    UP("dfc0", dfc0) UP("dfc2", dfc2) UP("du.w", frag32(duw->data, 256, 64, 27)) UP("du.b", dfrag32(dub->data, 256))
+    UP("dfc0", dfc0) UP("dfc2", dfc2) UP("du.w0", frag32(duw->data, 128, 64, 27)) UP("du.w1", frag32(duw->data + (size_t)128 * 64 * 27, 128, 64, 27))
+    UP("du.b0", dfrag32(dub->data, 128)) UP("du.b1", dfrag32(dub->data + 128, 128))
     {
         std::vector<float> wf(27 * 32);  // [tap][cin]
         for (int t = 0; t < 27; ++t)
@@ -283,6 +344,10 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
         UP("cb.ee", dfrag32(ee.data(), 256))
     }
 #undef UP
+    if ((rc = upload_i(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
+    if ((rc = upload_i(c, "steps.k3s1_4g", steps_conv(4, 4, 3, 1, 1, 3)))) return rc;    // kw-runs of up to 3 taps
+    if ((rc = upload_i(c, "steps.k4s2_8g", steps_conv(8, 4, 4, 2, 1, 4)))) return rc;    // kw-runs of up to 4 taps
+    if ((rc = upload_i(c, "steps.rows8", steps_rows8()))) return rc;
     return VQHIP_OK;
 }
 
@@ -367,19 +432,19 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 }
 
 // kernel instantiations -------------------------------------------------------------------
-//                         CIN COUT SI SO KS ST PD NW STREAM INMODE GIN RESID GOUT CSUM  PIXSHUF
-constexpr auto k_enc_down = conv_mfma32_k<16, 32, 8, 4, 4, 2, 1, 8, false, 0, 0, false, 8, false, false>;
-constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 4, 4, 3, 1, 1, 8, false, 1, 8, false, 8, false, false>;
-constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 4, 4, 3, 1, 1, 8, false, 1, 8, true, 0, true, false>;
-constexpr auto k_dec_stem = conv_mfma32_k<128, 64, 4, 4, 3, 1, 1, 4, true, 0, 0, false, 8, false, false>;
-constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 4, 4, 3, 1, 1, 4, true, 1, 8, false, 8, false, false>;
-constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 4, 4, 3, 1, 1, 4, true, 1, 8, true, 0, true, false>;
-constexpr auto k_dec_up = conv_mfma32_k<64, 256, 4, 4, 3, 1, 1, 4, true, 2, 0, false, 0, false, true>;
-constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB
-constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB
-constexpr size_t LDS_DEC_STEM = (size_t)(16 * 2 * 64) * 16;       // 32 KB
-constexpr size_t LDS_DEC_R64 = (size_t)(8 * 2 * 64) * 16;         // 16 KB
-constexpr size_t LDS_DEC_UP = (size_t)(8 * 8 * 64) * 16;          // 64 KB
+//                                          CIN COUT NPI NPO NW STREAM KWG INMODE GIN RESID GOUT CSUM  PIXSHUF
+constexpr auto k_enc_down = conv_mfma32_k<16, 32, 512, 64, 8, false, 4, 0, 0, false, 8, false, false>;
+constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false, 8, false, false>;
+constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true, 0, true, false>;
+constexpr auto k_dec_stem = conv_mfma32_k<128, 64, 64, 64, 8, true, 1, 0, 0, false, 8, false, false>;
+constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false, 8, false, false>;
+constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true, 0, true, false>;
+constexpr auto k_dec_up = conv_mfma32_k<64, 128, 64, 64, 8, true, 1, 2, 0, false, 0, false, true>;  // launched twice (cout halves)
+constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, resident
+constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
+constexpr size_t LDS_DEC_STEM = (size_t)2 * (16 * 2 * 64) * 16;   // 2 x 32 KB window
+constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
+constexpr size_t LDS_DEC_UP = (size_t)2 * (8 * 4 * 64) * 16;      // 2 x 32 KB
 constexpr size_t LDS_PROJ_VQ = (size_t)(16 * 8 * 64 + 4 * 4 * 64) * 16;  // 144 KB
 
 int init_kernel_attrs(vqhip_codec* c)
@@ -407,7 +472,8 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         ConvArgs A{};
         A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        L.run("enc_conv_first", [&] { hipLaunchKernelGGL(conv_first_k, dim3(g4), dim3(256), 0, s, A); });
+        A.n_steps = c->nsteps["steps.rows8"];
+        L.run("enc_conv_first", [&] { hipLaunchKernelGGL(conv_first_k, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8"]); });
     }
     {
         ConvArgs A{};
@@ -420,33 +486,38 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<false, true>), dim3(g4), dim3(256), 0, s, A); });
+        A.n_steps = c->nsteps["steps.rows8"];
+        L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<false, true>), dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
-        L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<true, false>), dim3(g4), dim3(256), 0, s, A); });
+        A.n_steps = c->nsteps["steps.rows8"];
+        L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<true, false>), dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"];
         A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
-        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down, dim3(g8), dim3(512), LDS_ENC_DOWN, s, A); });
+        A.n_steps = c->nsteps["steps.k4s2_8g"], A.n_taps = 64;
+        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down, dim3(g8), dim3(512), LDS_ENC_DOWN, s, A, (const int4*)w["steps.k4s2_8g"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1, dim3(g8), dim3(512), LDS_ENC_R32, s, A); });
+        A.n_steps = c->nsteps["steps.k3s1_4g"], A.n_taps = 27;
+        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.k3s1_4g"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
         A.out_csum = a["csum"], A.n_tiles = nt;
-        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A); });
+        A.n_steps = c->nsteps["steps.k3s1_4g"], A.n_taps = 27;
+        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.k3s1_4g"]); });
     }
     {
         VqArgs A{};
@@ -466,14 +537,15 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     auto& a = c->act;
     auto& w = c->dw;
     Launcher L{c, s, n};
-    const int g4 = (nt + 3) / 4;
+    const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
     L.run("gather_codes", [&] { hipLaunchKernelGGL(gather_codes_k, dim3(nt * 16), dim3(256), 0, s, d_idx, w["cb"], a["d_q"], n, nt); });
     {
         ConvArgs A{};
         A.in = a["d_q"], A.out = a["d_ystem"], A.wfrag = w["ds.w"], A.bias_frag = w["ds.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        L.run("dec_stem", [&] { hipLaunchKernelGGL(k_dec_stem, dim3(g4), dim3(256), LDS_DEC_STEM, s, A); });
+        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
+        L.run("dec_stem", [&] { hipLaunchKernelGGL(k_dec_stem, dim3(g8), dim3(512), LDS_DEC_STEM, s, A, (const int4*)w["steps.k3s1_4"]); });
     }
     {
         ConvArgs A{};
@@ -486,20 +558,26 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        L.run("dec_res64_conv1", [&] { hipLaunchKernelGGL(k_dec_r64c1, dim3(g4), dim3(256), LDS_DEC_R64, s, A); });
+        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
+        L.run("dec_res64_conv1", [&] { hipLaunchKernelGGL(k_dec_r64c1, dim3(g8), dim3(512), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
     }
     {
         ConvArgs A{};
         A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w"], A.bias_frag = w["r64c2.b"], A.skip = a["d_d2"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
         A.out_csum = a["csum"], A.n_tiles = nt;
-        L.run("dec_res64_conv2", [&] { hipLaunchKernelGGL(k_dec_r64c2, dim3(g4), dim3(256), LDS_DEC_R64, s, A); });
+        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
+        L.run("dec_res64_conv2", [&] { hipLaunchKernelGGL(k_dec_r64c2, dim3(g8), dim3(512), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
     }
     {
         ConvArgs A{};
-        A.in = a["d_x6"], A.out = a["d_ps"], A.wfrag = w["du.w"], A.bias_frag = w["du.b"];
+        A.in = a["d_x6"], A.out = a["d_ps"];
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt;
-        L.run("dec_up_conv", [&] { hipLaunchKernelGGL(k_dec_up, dim3(g4), dim3(256), LDS_DEC_UP, s, A); });
+        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
+        for (int half = 0; half < 2; ++half) {  // 256 couts as two 128-cout launches (register budget)
+            A.wfrag = w[half ? "du.w1" : "du.w0"], A.bias_frag = w[half ? "du.b1" : "du.b0"], A.mt_base = 4 * half;
+            L.run("dec_up_conv", [&] { hipLaunchKernelGGL(k_dec_up, dim3(g8), dim3(512), LDS_DEC_UP, s, A, (const int4*)w["steps.k3s1_4"]); });
+        }
     }
     L.run("dec_final", [&] {
         hipLaunchKernelGGL(final_conv_k, dim3((nt + 7) / 8), dim3(256), 0, s, a["d_ps"], w["df.w"], c->e_final_bias, d_out, n, nt);
