@@ -28,7 +28,9 @@
  *       "P16" (Cin == 16)        : 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15
  *       first conv (Cin == 1)    : K = (kd,kh) x {kw=0,1,2,pad}; invalid kw and the pad slot
  *                                  contribute fmaf(w,0,acc) / fmaf(0,0,acc).
- *       final conv (Cout == 1)   : natural ascending channel order.
+ *       final conv (Cout == 1)   : out = sum over valid taps ascending of P_tap, accumulated
+ *                                  from 0 with plain adds, P_tap = fmaf chain over cin ("P8")
+ *                                  from 0; then + bias.
  *   * GroupNorm statistics: fp64 accumulators, positions ascending then channels ascending;
  *     groups of 8 channels are the sum of two partials (low 4, high 4 channels);
  *     mean = S/N, var = fma(-mean,mean,Q/N) clamped at 0, rstd = 1/sqrt(var+1e-5) in fp64,
@@ -107,7 +109,6 @@ static void korder_p16(int* ord)
     for (int i = 0; i < 4; ++i)
         for (int q = 0; q < 4; ++q) ord[i * 4 + q] = 4 * q + i;
 }
-static void korder_nat(int cin, int* ord) { for (int c = 0; c < cin; ++c) ord[c] = c; }
 
 /* ---- conv3d, activations [C][S^3][LT] ----
  * CB output channels are computed together only for instruction-level parallelism; every
@@ -184,6 +185,43 @@ static void conv_first(const float* in /*[512][LT]*/, float* out /*[16][512][LT]
         }
         float* o = out + ((size_t)co * 512 + (od * 8 + oh) * 8 + ow) * LT;
         for (int l = 0; l < LT; ++l) o[l] = acc[l] + bias[co];
+    }
+}
+
+/* final conv (Cout = 1, Cin = 32, k3 p1 @8^3): per-tap partial dot products summed over taps */
+static void conv_final(const float* in /*[32][512][LT]*/, float* out /*[512][LT]*/, const float* W /*[1][32][27]*/, const float* bias)
+{
+    int p8[32];
+    korder_p8(32, p8);
+    for (int od = 0; od < 8; ++od)
+    for (int oh = 0; oh < 8; ++oh)
+    for (int ow = 0; ow < 8; ++ow) {
+        float s[LT];
+        for (int l = 0; l < LT; ++l) s[l] = 0.0f;
+        for (int kd = 0; kd < 3; ++kd) {
+            const int id = od - 1 + kd;
+            if (id < 0 || id >= 8) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh - 1 + kh;
+                if (ih < 0 || ih >= 8) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow - 1 + kw;
+                    if (iw < 0 || iw >= 8) continue;
+                    const int ip = (id * 8 + ih) * 8 + iw, tap = (kd * 3 + kh) * 3 + kw;
+                    float pt[LT];
+                    for (int l = 0; l < LT; ++l) pt[l] = 0.0f;
+                    for (int cc = 0; cc < 32; ++cc) {
+                        const int ci = p8[cc];
+                        const float w = W[ci * 27 + tap];
+                        const float* x = in + ((size_t)ci * 512 + ip) * LT;
+                        for (int l = 0; l < LT; ++l) pt[l] = fmaf(w, x[l], pt[l]);
+                    }
+                    for (int l = 0; l < LT; ++l) s[l] = s[l] + pt[l];
+                }
+            }
+        }
+        float* o = out + (size_t)((od * 8 + oh) * 8 + ow) * LT;
+        for (int l = 0; l < LT; ++l) o[l] = s[l] + bias[0];
     }
 }
 
@@ -386,8 +424,8 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
 static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0, int nl, float* out,
                         float* const* dbg, scratch_t* s)
 {
-    int p8_64[64], p8_128[128], nat32[32];
-    korder_p8(64, p8_64); korder_p8(128, p8_128); korder_nat(32, nat32);
+    int p8_64[64], p8_128[128];
+    korder_p8(64, p8_64); korder_p8(128, p8_128);
     const float* E = W[W_CODEBOOK];
     float* q = s->a; /* [128][64][LT] */
     for (int c = 0; c < 128; ++c)
@@ -427,7 +465,7 @@ static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0
             }
     if (dbg) dump(dbg[DBG_D_PS], ps, 32, 512, leaf0, nl);
     float* pre = s->d; /* [1][512][LT] */
-    conv3d(ps, pre, W[W_D_FINAL_W], W[W_D_FINAL_B], 32, 1, 8, 8, 3, 1, 1, nat32);
+    conv_final(ps, pre, W[W_D_FINAL_W], W[W_D_FINAL_B]);
     if (dbg) dump(dbg[DBG_D_PRE], pre, 1, 512, leaf0, nl);
     for (int p = 0; p < 512; ++p)
         for (int l = 0; l < nl; ++l) out[(size_t)(leaf0 + l) * 512 + p] = vq_sigmoid(pre[p * LT + l]);

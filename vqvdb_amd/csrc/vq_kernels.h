@@ -785,66 +785,101 @@ __global__ __launch_bounds__(256) void gather_codes_k(const uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------
 // D10/D11: Conv3d(32->1,k3,p1) @8^3 + sigmoid (VQVAE_v2.py:268,275), output leaf-major
 // [n][512] as the orchestrator's unpack loop expects (VQVAECodec.cpp:182-192).
-// One output channel -> no matrix shape: fp32 VALU, lane = leaf (two tiles per wave), a row of 8
-// outputs per lane in registers, weights through wave-uniform (scalar) loads.
+// One output channel has no GEMM N dimension, so the matrix shape is built from the TAPS:
+// input-stationary, per input position one MFMA block  P[tap(27 of 32 rows)][leaf] =
+// sum_cin W[tap][cin] * x[cin][leaf]  (16 x 32x32x2 MFMAs, K order P8), then each lane
+// scatter-adds its 16 tap partials into the outputs they belong to (out[pos - off(tap)]), which
+// live in a 3-slab (od ring) LDS accumulator per wave.  The 64 KB/leaf input is read exactly
+// once; an output slab is finished (bias, sigmoid, coalesced store) as soon as the input slab
+// after it has been consumed.  Accumulation order per output: valid taps ascending, each tap a
+// cin-chain from 0 (restated by the oracle's final conv).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void final_conv_k(const float* __restrict__ ps, const float* __restrict__ wfin /*[27][32]*/,
-                                                    float bias, float* __restrict__ out, int64_t n_leaves, int n_tiles)
+constexpr int FIN_SLAB = 64 * 33;          // floats per output slab (64 positions x (32 leaves + 1 pad))
+constexpr int FIN_LDS_WAVE = 3 * FIN_SLAB; // floats per wave
+
+__global__ __launch_bounds__(256) void final_mfma_k(const float* __restrict__ ps, const float* __restrict__ wfrag, float bias,
+                                                    float* __restrict__ out, int64_t n_leaves, int n_tiles)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile0 = (blockIdx.x * 4 + wave) * 2;
-    if (tile0 >= n_tiles) return;
-    int tile = tile0 + (lane >> 5);
-    const bool act = tile < n_tiles;
-    if (!act) tile = n_tiles - 1;
-    const int j = lane & 31;
-    const f32x4* in4 = (const f32x4*)ps + (size_t)tile * 512 * 8 * 32 + j;
-    const f32x4* w4 = (const f32x4*)wfin;
-    const int64_t leaf = (int64_t)tile * 32 + j;
-    for (int od = 0; od < 8; ++od)
-        for (int oh = 0; oh < 8; ++oh) {
-            float acc[8];
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;  // no workgroup barriers below: waves are independent
+    float* ring = (float*)smem_raw + wave * FIN_LDS_WAVE;
+    const int j = lane & 31, q = lane >> 5;
+    for (int i = lane; i < FIN_LDS_WAVE; i += 64) ring[i] = 0.0f;
+
+    // per-lane constants of the 16 taps this lane's accumulator registers hold
+    unsigned vmask[16];  // valid input coordinates per axis: bits 16..23 id, 8..15 ih, 0..7 iw
+    int poff[16];        // (kh-1)*8 + (kw-1)
+    int kdr[16];
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) acc[ow] = 0.0f;
-            const int kd0 = od == 0 ? 1 : 0, kd1 = od == 7 ? 2 : 3;
-            const int kh0 = oh == 0 ? 1 : 0, kh1 = oh == 7 ? 2 : 3;
-            for (int kd = kd0; kd < kd1; ++kd)
-                for (int kh = kh0; kh < kh1; ++kh) {
-                    const int id = od + kd - 1, ih = oh + kh - 1;
-                    const f32x4* wt = w4 + (kd * 3 + kh) * 3 * 8;
+    for (int r = 0; r < 16; ++r) {
+        const int t = (r & 3) + 8 * (r >> 2) + 4 * q;
+        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        const unsigned md = kd == 0 ? 0x7Fu : (kd == 1 ? 0xFFu : 0xFEu);
+        const unsigned mh = kh == 0 ? 0x7Fu : (kh == 1 ? 0xFFu : 0xFEu);
+        const unsigned mw = kw == 0 ? 0x7Fu : (kw == 1 ? 0xFFu : 0xFEu);
+        vmask[r] = t < 27 ? (md << 16) | (mh << 8) | mw : 0u;
+        poff[r] = (kh - 1) * 8 + (kw - 1);
+        kdr[r] = kd;
+    }
+    f32x4 wa[4];
 #pragma unroll
-                    for (int iw = 0; iw < 8; ++iw)
+    for (int u = 0; u < 4; ++u) wa[u] = ((const f32x4*)wfrag)[u * 64 + lane];
+    const f32x4* in4 = (const f32x4*)ps + (size_t)tile * 512 * 8 * 32 + q * 32 + j;
+    f32x4 bn[4];
 #pragma unroll
-                        for (int g = 0; g < 8; ++g) {
-                            const f32x4 x = in4[((size_t)((id * 8 + ih) * 8 + iw) * 8 + g) * 32];
+    for (int u = 0; u < 4; ++u) bn[u] = in4[u * 64];
+
+    for (int id = 0; id < 8; ++id) {
+        for (int p = 0; p < 64; ++p) {
+            f32x4 bc[4];
 #pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) {
-                                const int ow = iw - kw + 1;
-                                if (ow < 0 || ow > 7) continue;
-                                const f32x4 w = wt[kw * 8 + g];
-                                acc[ow] = __builtin_fmaf(w.x, x.x, acc[ow]);
-                                acc[ow] = __builtin_fmaf(w.y, x.y, acc[ow]);
-                                acc[ow] = __builtin_fmaf(w.z, x.z, acc[ow]);
-                                acc[ow] = __builtin_fmaf(w.w, x.w, acc[ow]);
-                            }
-                        }
-                }
-            if (act && leaf < n_leaves) {
-                f32x4 o0, o1;
-                o0.x = vq_sigmoid(acc[0] + bias);
-                o0.y = vq_sigmoid(acc[1] + bias);
-                o0.z = vq_sigmoid(acc[2] + bias);
-                o0.w = vq_sigmoid(acc[3] + bias);
-                o1.x = vq_sigmoid(acc[4] + bias);
-                o1.y = vq_sigmoid(acc[5] + bias);
-                o1.z = vq_sigmoid(acc[6] + bias);
-                o1.w = vq_sigmoid(acc[7] + bias);
-                f32x4* o = (f32x4*)(out + leaf * 512 + (od * 8 + oh) * 8);
-                o[0] = o0;
-                o[1] = o1;
+            for (int u = 0; u < 4; ++u) bc[u] = bn[u];
+            const int pn = min(id * 64 + p + 1, 511);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bn[u] = in4[(size_t)pn * 8 * 32 + u * 64];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = mfma32(wa[u].x, bc[u].x, acc);
+                acc = mfma32(wa[u].y, bc[u].y, acc);
+                acc = mfma32(wa[u].z, bc[u].z, acc);
+                acc = mfma32(wa[u].w, bc[u].w, acc);
+            }
+            // scatter-add the tap partials: out(od,oh,ow) with od = id+1-kd, (oh,ow) = p - poff
+            const int ih = p >> 3, iw = p & 7;
+            float old[16];
+            int addr[16];
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ok[r] = ((vmask[r] >> (16 + id)) & (vmask[r] >> (8 + ih)) & (vmask[r] >> iw) & 1u) != 0;
+                const int od = id + 1 - kdr[r];
+                const int slot = od - 3 * ((od * 11) >> 5);  // od % 3 for od in [0,8)
+                addr[r] = ok[r] ? (slot * 64 + p - poff[r]) * 33 + j : 0;
+                old[r] = ok[r] ? ring[addr[r]] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) ring[addr[r]] = old[r] + acc[r];
+        }
+        // output slabs whose last contributing input slab is `id`: od = id-1, and od = 7 at the end
+#pragma unroll 1
+        for (int od = (id >= 1 ? id - 1 : 8); od <= (id == 7 ? 7 : id - 1); ++od) {
+            const int slot = od % 3;
+            for (int l = 0; l < 32; ++l) {
+                const int a = (slot * 64 + lane) * 33 + l;
+                const float v = ring[a];
+                ring[a] = 0.0f;
+                const int64_t leaf = (int64_t)tile * 32 + l;
+                if (leaf < n_leaves) out[leaf * 512 + od * 64 + lane] = vq_sigmoid(v + bias);
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_up_conv", {28311552.0 + 2048, 28311552.0 * 0.578704 + 2048}},  // per launch: half of the 256 couts
-        {"dec_final", {2.0 * 442368, 2.0 * 442368 * 0.7703}},
+        {"dec_final", {2.0 * 442368, 2.0 * 442368 * 0.7703}},  // algorithmic; the kernel issues 512*32*32 MACs/leaf as MFMA
     };
     return m;
 }
@@ -326,10 +326,11 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("dfc0", dfc0) UP("dfc2", dfc2) UP("du.w0", frag32(duw->data, 128, 64, 27)) UP("du.w1", frag32(duw->data + (size_t)128 * 64 * 27, 128, 64, 27))
     UP("du.b0", dfrag32(dub->data, 128)) UP("du.b1", dfrag32(dub->data + 128, 128))
     {
-        std::vector<float> wf(27 * 32);  // [tap][cin]
+        // final conv as a [32 taps (27 real) x 32 cin] matrix: rows = taps -> A fragments of one 32x32 tile
+        std::vector<float> wt(32 * 32, 0.0f);  // [tap][cin][1]
         for (int t = 0; t < 27; ++t)
-            for (int ci = 0; ci < 32; ++ci) wf[t * 32 + ci] = dfw->data[ci * 27 + t];
-        UP("df.w", wf)
+            for (int ci = 0; ci < 32; ++ci) wt[t * 32 + ci] = dfw->data[ci * 27 + t];
+        UP("df.w", frag32(wt.data(), 32, 32, 1))
         c->e_final_bias = dfb->data[0];
     }
     UP("cb", cb) UP("cb.frag", frag32(cb->data, 256, 128, 1))
@@ -445,6 +446,7 @@ constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, res
 constexpr size_t LDS_DEC_STEM = (size_t)2 * (16 * 2 * 64) * 16;   // 2 x 32 KB window
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
 constexpr size_t LDS_DEC_UP = (size_t)2 * (8 * 4 * 64) * 16;      // 2 x 32 KB
+constexpr size_t LDS_DEC_FINAL = (size_t)4 * FIN_LDS_WAVE * sizeof(float);  // 99 KB: 4 waves x 3-slab output ring
 constexpr size_t LDS_PROJ_VQ = (size_t)(16 * 8 * 64 + 4 * 4 * 64) * 16;  // 144 KB
 
 int init_kernel_attrs(vqhip_codec* c)
@@ -454,6 +456,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, proj_vq_k<8>, LDS_PROJ_VQ))) return rc;
+    if ((rc = set_lds(c, final_mfma_k, LDS_DEC_FINAL))) return rc;
     return VQHIP_OK;
 }
 
@@ -580,7 +583,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         }
     }
     L.run("dec_final", [&] {
-        hipLaunchKernelGGL(final_conv_k, dim3((nt + 7) / 8), dim3(256), 0, s, a["d_ps"], w["df.w"], c->e_final_bias, d_out, n, nt);
+        hipLaunchKernelGGL(final_mfma_k, dim3(g4), dim3(256), LDS_DEC_FINAL, s, a["d_ps"], w["df.w"], c->e_final_bias, d_out, n, nt);
     });
     return L.rc;
 }
