@@ -28,7 +28,7 @@
  *       "P16" (Cin == 16)        : 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15
  *       first conv (Cin == 1)    : K = (kd,kh) x {kw=0,1,2,pad}; invalid kw and the pad slot
  *                                  contribute fmaf(w,0,acc) / fmaf(0,0,acc).
- *       final conv (Cout == 1)   : out = sum over valid taps ascending of P_tap, accumulated
+ *       decoder stem, final conv : out = sum over valid taps ascending of P_tap, accumulated
  *                                  from 0 with plain adds, P_tap = fmaf chain over cin ("P8")
  *                                  from 0; then + bias.
  *   * GroupNorm statistics: fp64 accumulators, positions ascending then channels ascending;
@@ -185,6 +185,45 @@ static void conv_first(const float* in /*[512][LT]*/, float* out /*[16][512][LT]
         }
         float* o = out + ((size_t)co * 512 + (od * 8 + oh) * 8 + ow) * LT;
         for (int l = 0; l < LT; ++l) o[l] = acc[l] + bias[co];
+    }
+}
+
+/* k3 p1 conv as a sum of per-tap partial dot products: out = (sum over valid taps ascending of P_tap,
+ * plain adds from 0) + bias, P_tap = fmaf chain over cin in `kord` from 0.  This is the order of the
+ * decoder stem (per-(tap,code) table lookups on the GPU) and of the final conv (MFMA tap partials). */
+static void conv_tapsum(const float* in, float* out, const float* W, const float* bias, int CIN, int COUT, int S, const int* kord)
+{
+    const int NP = S * S * S;
+    for (int co = 0; co < COUT; ++co)
+    for (int od = 0; od < S; ++od)
+    for (int oh = 0; oh < S; ++oh)
+    for (int ow = 0; ow < S; ++ow) {
+        float s[LT];
+        for (int l = 0; l < LT; ++l) s[l] = 0.0f;
+        for (int kd = 0; kd < 3; ++kd) {
+            const int id = od - 1 + kd;
+            if (id < 0 || id >= S) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh - 1 + kh;
+                if (ih < 0 || ih >= S) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow - 1 + kw;
+                    if (iw < 0 || iw >= S) continue;
+                    const int ip = (id * S + ih) * S + iw, tap = (kd * 3 + kh) * 3 + kw;
+                    float pt[LT];
+                    for (int l = 0; l < LT; ++l) pt[l] = 0.0f;
+                    for (int cc = 0; cc < CIN; ++cc) {
+                        const int ci = kord[cc];
+                        const float w = W[((size_t)co * CIN + ci) * 27 + tap];
+                        const float* x = in + ((size_t)ci * NP + ip) * LT;
+                        for (int l = 0; l < LT; ++l) pt[l] = fmaf(w, x[l], pt[l]);
+                    }
+                    for (int l = 0; l < LT; ++l) s[l] = s[l] + pt[l];
+                }
+            }
+        }
+        float* o = out + ((size_t)co * NP + (od * S + oh) * S + ow) * LT;
+        for (int l = 0; l < LT; ++l) o[l] = s[l] + bias[co];
     }
 }
 
@@ -435,7 +474,7 @@ static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0
                 q[((size_t)c * 64 + p) * LT + l] = E[k * 128 + c];
             }
     float* y = s->b;
-    conv3d(q, y, W[W_D_STEM_W], W[W_D_STEM_B], 128, 64, 4, 4, 3, 1, 1, p8_128);
+    conv_tapsum(q, y, W[W_D_STEM_W], W[W_D_STEM_B], 128, 64, 4, p8_128);
     if (dbg) dump(dbg[DBG_D_YSTEM], y, 64, 64, leaf0, nl);
     float mean[8 * LT], rstd[8 * LT];
     gn_stats(y, 64, 8, 64, mean, rstd);

@@ -346,6 +346,13 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
             en = en2;
             ++si;
         } while (!last);
+        f32x4 sk[RESID ? 8 : 1][2];
+        if (RESID) {  // issue all residual loads before any of the epilogue math
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) sk[ow][sb] = skip4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb];
+        }
 #pragma unroll
         for (int ow = 0; ow < 8; ++ow)
 #pragma unroll
@@ -353,9 +360,8 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                 const size_t o = ((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb;
                 f32x4 v = acc[ow][sb] + bias4;
                 if (RESID) {
-                    const f32x4 sk = skip4[o];
                     const f32x4 u = v * 0.1f;
-                    v = sk + u;
+                    v = sk[ow][sb] + u;
                 }
                 out4[o] = v;
                 if (STATS) {
@@ -546,6 +552,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
         } while (!last);
 
         // ---- epilogue for output position po ----
+        f32x4 skv[RESID ? NMT : 1][4];
+        if (RESID) {  // issue all residual loads before any of the epilogue math
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    skv[mt][g] = ((const f32x4*)A.skip)[(((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j];
+        }
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
@@ -559,9 +573,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
                 const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
                 if (RESID) {
-                    const f32x4 sk = ((const f32x4*)A.skip)[o];
                     const f32x4 u = v * 0.1f;
-                    v = sk + u;
+                    v = skv[mt][g] + u;
                 }
                 if (!PIXSHUF && active) ((f32x4*)A.out)[o] = v;
                 if (GOUT > 0) {
@@ -724,6 +737,9 @@ __global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
         float best = __builtin_inff();
         int bk = 0;
         for (int ct = 0; ct < 8; ++ct) {
+            f32x4 eev[4];  // ||e||^2 of this lane's 16 codes: requested before the 64 MFMAs that hide the latency
+#pragma unroll
+            for (int g = 0; g < 4; ++g) eev[g] = ee4[(ct * 2 + q) * 4 + g];
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.0f;
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
                 }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 ee = ee4[(ct * 2 + q) * 4 + g];
+                const f32x4 ee = eev[g];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float een = i == 0 ? ee.x : (i == 1 ? ee.y : (i == 2 ? ee.z : ee.w));
@@ -762,24 +778,98 @@ __global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
-// D0: embedding gather (VQVAE_v2.py:373-375): q[leaf][c][pos] = E[idx[leaf][pos]][c], L4 layout.
-// One wave per (tile, position); lane (leaf j, half h) copies every other float4 of its row.
+// D0+D1: embedding gather (VQVAE_v2.py:373-375) + decoder stem Conv3d(128->64,k3,p1) (:257).
+// The stem only ever sees the 256 codebook rows, so by linearity
+//     y[co][p] = bias + sum_{valid taps} T[tap][idx[p+tap]][co],   T[tap][k][co] = sum_cin W[co][cin][tap] * E[k][cin]
+// T (27 x 256 x 64 fp32 = 1.77 MB, L2-resident) is built once per codec from the weights by
+// build_stem_lut_k with the contract's cin-chain ("P8", from 0); the per-leaf work drops from 14.2 M
+// MACs to ~1000 table-row adds per leaf position and the 32 KiB/leaf gathered tensor never exists.
+// Accumulation order per output: valid taps ascending, plain adds from 0, then + bias (oracle:
+// conv_tapsum).  Also produces the GroupNorm(8,64) statistics of the output.
+// Lane (leaf j, half h) owns couts [32h, 32h+32).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_codes_k(const uint8_t* __restrict__ idx, const float* __restrict__ E,
-                                                      float* __restrict__ qout, int64_t n_leaves, int n_tiles)
+__global__ __launch_bounds__(64) void build_stem_lut_k(const float* __restrict__ W /*[64][128][27]*/, const float* __restrict__ E /*[256][128]*/,
+                                                       float* __restrict__ T /*[27][256][64]*/)
 {
+    const int tap = blockIdx.x / 256, k = blockIdx.x % 256, co = threadIdx.x;
+    float p = 0.0f;
+    for (int cc = 0; cc < 128; ++cc) {
+        const int ci = (cc & ~7) + ((cc & 1) ? 4 : 0) + ((cc & 7) >> 1);  // P8: 0,4,1,5,2,6,3,7
+        p = __builtin_fmaf(W[((size_t)co * 128 + ci) * 27 + tap], E[k * 128 + ci], p);
+    }
+    T[((size_t)tap * 256 + k) * 64 + co] = p;
+}
+
+__global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ idx, const float* __restrict__ T, const float* __restrict__ bias,
+                                                  float* __restrict__ out, float* __restrict__ out_mean, float* __restrict__ out_rstd,
+                                                  const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles)
+{
+    __shared__ uint8_t sidx[4][64 * 32];
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t tile = w >> 6;
-    const int p = (int)(w & 63);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
     if (tile >= n_tiles) return;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t leaf = tile * 32 + j;
-    const int k = leaf < n_leaves ? idx[leaf * 64 + p] : 0;
-    const f32x4* e4 = (const f32x4*)E + (size_t)k * 32;
-    f32x4* o4 = (f32x4*)qout + ((size_t)tile * 64 + p) * 32 * 32 + j;
-#pragma unroll 4
-    for (int g = h; g < 32; g += 2) o4[(size_t)g * 32] = e4[g];
+    const int64_t leaf = (int64_t)tile * 32 + j;
+    uint8_t* my = sidx[wave];
+    for (int p = h; p < 64; p += 2) my[p * 32 + j] = leaf < n_leaves ? idx[leaf * 64 + p] : 0;
+    // (same wave writes and reads its own LDS region: program order suffices)
+    const f32x4* T4 = (const f32x4*)T + h * 8;
+    f32x4 b4[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) b4[g] = ((const f32x4*)bias)[h * 8 + g];
+    GnAcc st[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) st[g].init();
+    f32x4* out4 = (f32x4*)out + (size_t)tile * 64 * 16 * 32 + (size_t)h * 8 * 32 + j;
+
+    int4 e = steps[0];
+    int4 en = steps[1];
+    f32x4 rn[8];
+    {
+        const int k = my[e.x * 32 + j];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) rn[g] = T4[((size_t)e.y * 256 + k) * 16 + g];
+    }
+    int si = 0;
+    for (int po = 0; po < 64; ++po) {
+        f32x4 acc[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc[g] = (f32x4){0, 0, 0, 0};
+        bool last;
+        do {
+            f32x4 rc[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) rc[g] = rn[g];
+            const int4 en2 = steps[si + 2 < n_steps ? si + 2 : n_steps - 1];
+            const int kn = my[en.x * 32 + j];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) rn[g] = T4[((size_t)en.y * 256 + kn) * 16 + g];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) acc[g] = acc[g] + rc[g];
+            last = (e.w & 2) != 0;
+            e = en;
+            en = en2;
+            ++si;
+        } while (!last);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 v = acc[g] + b4[g];
+            out4[((size_t)po * 16 + g) * 32] = v;
+            st[g].add(v.x);
+            st[g].add(v.y);
+            st[g].add(v.z);
+            st[g].add(v.w);
+        }
+    }
+    // GroupNorm(8,64): group = 8 channels = two 4-channel partials (low + high), both owned by this lane
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float m, r;
+        gn_finish(st[2 * k].s + st[2 * k + 1].s, st[2 * k].q + st[2 * k + 1].q, 1.0 / 512.0, m, r);
+        out_mean[((size_t)tile * 8 + h * 4 + k) * 32 + j] = m;
+        out_rstd[((size_t)tile * 8 + h * 4 + k) * 32 + j] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

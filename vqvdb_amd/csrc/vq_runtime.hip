@@ -48,7 +48,7 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"enc_res32_conv1", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
         {"enc_res32_conv2", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
         {"enc_proj_vq", {2.0 * (262144 + 2097152 + 512), 2.0 * (262144 + 2097152 + 512)}},
-        {"dec_stem", {2.0 * 14155776, 2.0 * 14155776 * 0.578704}},
+        {"dec_stem", {0.0, 0.0}},  // table lookups: the 14.2 M MAC/leaf of the reference op are not executed (stem_lut_k)
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_up_conv", {28311552.0 + 2048, 28311552.0 * 0.578704 + 2048}},  // per launch: half of the 256 couts
@@ -320,7 +320,7 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("r32g1.w", r32g1w) UP("r32g1.b", r32g1b) UP("r32c1.w", frag32(r32c1w->data, 32, 32, 27)) UP("r32c1.b", dfrag32(r32c1b->data, 32))
     UP("r32g2.w", r32g2w) UP("r32g2.b", r32g2b) UP("r32c2.w", frag32(r32c2w->data, 32, 32, 27)) UP("r32c2.b", dfrag32(r32c2b->data, 32))
     UP("efc0", efc0) UP("efc2", efc2) UP("ep.w", frag32(epw->data, 128, 32, 1)) UP("ep.b", dfrag32(epb->data, 128))
-    UP("ds.w", frag32(dsw->data, 64, 128, 27)) UP("ds.b", dfrag32(dsb->data, 64)) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
+    UP("ds.w", dsw) UP("ds.b", dsb) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
     UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
     UP("dfc0", dfc0) UP("dfc2", dfc2) UP("du.w0", frag32(duw->data, 128, 64, 27)) UP("du.w1", frag32(duw->data + (size_t)128 * 64 * 27, 128, 64, 27))
@@ -349,6 +349,15 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     if ((rc = upload_i(c, "steps.k3s1_4g", steps_conv(4, 4, 3, 1, 1, 3)))) return rc;    // kw-runs of up to 3 taps
     if ((rc = upload_i(c, "steps.k4s2_8g", steps_conv(8, 4, 4, 2, 1, 4)))) return rc;    // kw-runs of up to 4 taps
     if ((rc = upload_i(c, "steps.rows8", steps_rows8()))) return rc;
+    {
+        // decoder stem as a per-(tap, code) partial-sum table (stem_lut_k), built on the device once
+        float* T = nullptr;
+        HIPCHK(c, hipMalloc(&T, (size_t)27 * 256 * 64 * sizeof(float)));
+        c->dw["ds.lut"] = T;
+        hipLaunchKernelGGL(build_stem_lut_k, dim3(27 * 256), dim3(64), 0, c->stream, c->dw["ds.w"], c->dw["cb"], T);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return VQHIP_OK;
 }
 
@@ -359,7 +368,7 @@ struct ActSpec {
 };
 const ActSpec kActs[] = {
     {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
-    {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},    {"e_z", 128, 64},   {"d_q", 128, 64},
+    {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},    {"e_z", 128, 64},
     {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},   {"d_ps", 32, 512},
     {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64},
 };
@@ -437,13 +446,11 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 constexpr auto k_enc_down = conv_mfma32_k<16, 32, 512, 64, 8, false, 4, 0, 0, false, 8, false, false>;
 constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false, 8, false, false>;
 constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true, 0, true, false>;
-constexpr auto k_dec_stem = conv_mfma32_k<128, 64, 64, 64, 8, true, 1, 0, 0, false, 8, false, false>;
 constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false, 8, false, false>;
 constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true, 0, true, false>;
 constexpr auto k_dec_up = conv_mfma32_k<64, 128, 64, 64, 8, true, 1, 2, 0, false, 0, false, true>;  // launched twice (cout halves)
 constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
-constexpr size_t LDS_DEC_STEM = (size_t)2 * (16 * 2 * 64) * 16;   // 2 x 32 KB window
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
 constexpr size_t LDS_DEC_UP = (size_t)2 * (8 * 4 * 64) * 16;      // 2 x 32 KB
 constexpr size_t LDS_DEC_FINAL = (size_t)4 * FIN_LDS_WAVE * sizeof(float);  // 99 KB: 4 waves x 3-slab output ring
@@ -542,14 +549,10 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
-    L.run("gather_codes", [&] { hipLaunchKernelGGL(gather_codes_k, dim3(nt * 16), dim3(256), 0, s, d_idx, w["cb"], a["d_q"], n, nt); });
-    {
-        ConvArgs A{};
-        A.in = a["d_q"], A.out = a["d_ystem"], A.wfrag = w["ds.w"], A.bias_frag = w["ds.b"];
-        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
-        L.run("dec_stem", [&] { hipLaunchKernelGGL(k_dec_stem, dim3(g8), dim3(512), LDS_DEC_STEM, s, A, (const int4*)w["steps.k3s1_4"]); });
-    }
+    L.run("dec_stem", [&] {
+        hipLaunchKernelGGL(stem_lut_k, dim3(g4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
+                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt);
+    });
     {
         ConvArgs A{};
         A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
