@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""MFMA utilisation / effective clock per kernel from a rocprofv3 --pmc pass (rocpd sqlite):
+counters GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
+SQ_ACTIVE_INST_ANY SQ_WAIT_ANY.  GRBM_GUI_ACTIVE is summed over the 8 XCDs, MFMA busy over the
+1024 SIMDs -> clock = GUI/8/duration, mfma_util = MFMA_BUSY / (GUI/8 * 1024)."""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select kernel_name, counter_name, avg(value), avg(end-start) from counters_collection group by kernel_name, counter_name").fetchall()
+d = {}
+for k, c, v, dur in rows:
+    k = re.sub(r"\(.*", "", k).replace("void ", "")
+    if "at::" in k or "rocclr" in k:
+        continue
+    d.setdefault(k, {})[c] = v
+    d[k]["dur"] = dur
+print(f"{'kernel':78s} {'avg_us':>9s} {'clk_GHz':>8s} {'mfma_util':>9s} {'wait_inst':>9s} {'wait_any':>9s} {'active':>7s}")
+for k, v in sorted(d.items(), key=lambda kv: -kv[1]["dur"]):
+    g = v.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    wc = max(v.get("SQ_WAVE_CYCLES", 0), 1)
+    print(f"{k[:78]:78s} {v['dur'] / 1e3:9.1f} {g / max(v['dur'], 1):8.2f} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(g * 1024, 1):9.3f} "
+          f"{v.get('SQ_WAIT_INST_ANY', 0) / wc:9.2f} {v.get('SQ_WAIT_ANY', 0) / wc:9.2f} {v.get('SQ_ACTIVE_INST_ANY', 0) / wc:7.2f}")

@@ -77,12 +77,12 @@ struct vqhip_codec {
     std::map<std::string, float*> act;  // named activation buffers inside ws
     std::map<std::string, std::pair<int, int>> act_shape;
 
-    // staging
-    void* pin_in = nullptr;
-    void* pin_out = nullptr;
-    size_t pin_in_bytes = 0, pin_out_bytes = 0;
-    float* dev_leaves = nullptr;  // chunk * 512 floats
-    uint8_t* dev_idx = nullptr;   // chunk * 64 bytes
+    // host-pointer entry points: two I/O slots so H2D(i+1), compute(i) and D2H(i-1) overlap
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    void* pin_out[2] = {nullptr, nullptr};   // pinned landing zone for results (chunk * 2048 B each)
+    float* dev_leaves[2] = {nullptr, nullptr};  // chunk * 512 floats
+    uint8_t* dev_idx[2] = {nullptr, nullptr};   // chunk * 64 bytes
     int64_t dev_io_leaves = 0;
 
     // profiling
@@ -593,17 +593,74 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
 
 int ensure_io(vqhip_codec* c, int64_t n)
 {
+    if (!c->s_in) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
     if (n <= c->dev_io_leaves) return VQHIP_OK;
-    if (c->dev_leaves) hipFree(c->dev_leaves);
-    if (c->dev_idx) hipFree(c->dev_idx);
-    if (c->pin_in) hipHostFree(c->pin_in);
-    if (c->pin_out) hipHostFree(c->pin_out);
-    c->dev_leaves = nullptr, c->dev_idx = nullptr, c->pin_in = nullptr, c->pin_out = nullptr, c->dev_io_leaves = 0;
-    HIPCHK(c, hipMalloc(&c->dev_leaves, (size_t)n * 512 * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->dev_idx, (size_t)n * 64));
-    HIPCHK(c, hipHostMalloc(&c->pin_in, (size_t)n * 512 * sizeof(float), hipHostMallocDefault));
-    HIPCHK(c, hipHostMalloc(&c->pin_out, (size_t)n * 512 * sizeof(float), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) {
+        if (c->dev_leaves[i]) hipFree(c->dev_leaves[i]);
+        if (c->dev_idx[i]) hipFree(c->dev_idx[i]);
+        if (c->pin_out[i]) hipHostFree(c->pin_out[i]);
+        c->dev_leaves[i] = nullptr, c->dev_idx[i] = nullptr, c->pin_out[i] = nullptr;
+    }
+    c->dev_io_leaves = 0;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipMalloc(&c->dev_leaves[i], (size_t)n * 512 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->dev_idx[i], (size_t)n * 64));
+        HIPCHK(c, hipHostMalloc(&c->pin_out[i], (size_t)n * 512 * sizeof(float), hipHostMallocDefault));
+    }
     c->dev_io_leaves = n;
+    return VQHIP_OK;
+}
+
+// Host-pointer pipeline (the path the reference orchestrator calls, VQVAECodec.cpp:120,178).
+// Chunk i: H2D on s_in -> kernels on the compute stream -> D2H into pinned memory on s_out; the host
+// thread copies chunk i-1's result to the caller while the GPU works on chunk i.  encode: in = leaves
+// (2048 B/leaf), out = indices (64 B/leaf); decode: the reverse.
+int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out, int64_t n)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t step = std::min(c->chunk, n);
+    int rc = ensure_io(c, step);
+    if (rc) return rc;
+    const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
+    int64_t prev_off = -1, prev_m = 0;
+    int prev_slot = 0, i = 0;
+    auto drain = [&]() -> int {
+        if (prev_off < 0) return VQHIP_OK;
+        HIPCHK(c, hipEventSynchronize(c->ev_out[prev_slot]));
+        std::memcpy(static_cast<char*>(out) + (size_t)prev_off * out_b, c->pin_out[prev_slot], (size_t)prev_m * out_b);
+        prev_off = -1;
+        return VQHIP_OK;
+    };
+    for (int64_t o = 0; o < n; o += step, ++i) {
+        const int64_t m = std::min(step, n - o);
+        const int slot = i & 1;
+        void* d_in = is_encode ? (void*)c->dev_leaves[slot] : (void*)c->dev_idx[slot];
+        void* d_out = is_encode ? (void*)c->dev_idx[slot] : (void*)c->dev_leaves[slot];
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0));   // slot's previous input consumed
+        HIPCHK(c, hipMemcpyAsync(d_in, static_cast<const char*>(in) + (size_t)o * in_b, (size_t)m * in_b, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipEventRecord(c->ev_in[slot], c->s_in));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[slot], 0));  // slot's previous output drained to pinned
+        rc = is_encode ? encode_chunk(c, c->dev_leaves[slot], m, c->dev_idx[slot], c->stream, c->debug)
+                       : decode_chunk(c, c->dev_idx[slot], m, c->dev_leaves[slot], c->stream);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_done[slot], c->stream));
+        if ((rc = drain())) return rc;  // chunk i-1 -> caller, overlapped with chunk i on the GPU
+        HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_done[slot], 0));
+        HIPCHK(c, hipMemcpyAsync(c->pin_out[slot], d_out, (size_t)m * out_b, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(c, hipEventRecord(c->ev_out[slot], c->s_out));
+        prev_off = o, prev_m = m, prev_slot = slot;
+    }
+    if ((rc = drain())) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VQHIP_OK;
 }
 
@@ -674,10 +731,16 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->dw) hipFree(kv.second);
     if (c->ws) hipFree(c->ws);
-    if (c->dev_leaves) hipFree(c->dev_leaves);
-    if (c->dev_idx) hipFree(c->dev_idx);
-    if (c->pin_in) hipHostFree(c->pin_in);
-    if (c->pin_out) hipHostFree(c->pin_out);
+    for (int i = 0; i < 2; ++i) {
+        if (c->dev_leaves[i]) hipFree(c->dev_leaves[i]);
+        if (c->dev_idx[i]) hipFree(c->dev_idx[i]);
+        if (c->pin_out[i]) hipHostFree(c->pin_out[i]);
+        if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
+        if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
+        if (c->ev_out[i]) hipEventDestroy(c->ev_out[i]);
+    }
+    if (c->s_in) hipStreamDestroy(c->s_in);
+    if (c->s_out) hipStreamDestroy(c->s_out);
     for (auto& t : c->timers) {
         hipEventDestroy(t.start);
         hipEventDestroy(t.stop);
@@ -733,42 +796,14 @@ int vqhip_encode(vqhip_codec* c, const float* leaves, int64_t n, uint8_t* indice
 {
     if (!c) return VQHIP_ERR_INVALID;
     if (!leaves || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "encode: null pointer or n_leaves < 1");
-    HIPCHK(c, hipSetDevice(c->device));
-    const int64_t step = std::min(c->chunk, n);
-    int rc = ensure_io(c, step);
-    if (rc) return rc;
-    for (int64_t o = 0; o < n; o += step) {
-        const int64_t m = std::min(step, n - o);
-        std::memcpy(c->pin_in, leaves + o * 512, (size_t)m * 512 * sizeof(float));
-        HIPCHK(c, hipMemcpyAsync(c->dev_leaves, c->pin_in, (size_t)m * 512 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        rc = encode_chunk(c, c->dev_leaves, m, c->dev_idx, c->stream, c->debug);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->pin_out, c->dev_idx, (size_t)m * 64, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        std::memcpy(indices + o * 64, c->pin_out, (size_t)m * 64);
-    }
-    return VQHIP_OK;
+    return run_host_pipeline(c, true, leaves, indices, n);
 }
 
 int vqhip_decode(vqhip_codec* c, const uint8_t* indices, int64_t n, float* leaves)
 {
     if (!c) return VQHIP_ERR_INVALID;
     if (!leaves || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode: null pointer or n_leaves < 1");
-    HIPCHK(c, hipSetDevice(c->device));
-    const int64_t step = std::min(c->chunk, n);
-    int rc = ensure_io(c, step);
-    if (rc) return rc;
-    for (int64_t o = 0; o < n; o += step) {
-        const int64_t m = std::min(step, n - o);
-        std::memcpy(c->pin_in, indices + o * 64, (size_t)m * 64);
-        HIPCHK(c, hipMemcpyAsync(c->dev_idx, c->pin_in, (size_t)m * 64, hipMemcpyHostToDevice, c->stream));
-        rc = decode_chunk(c, c->dev_idx, m, c->dev_leaves, c->stream);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->pin_out, c->dev_leaves, (size_t)m * 512 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        std::memcpy(leaves + o * 512, c->pin_out, (size_t)m * 512 * sizeof(float));
-    }
-    return VQHIP_OK;
+    return run_host_pipeline(c, false, indices, leaves, n);
 }
 
 int vqhip_debug_enable(vqhip_codec* c, int enable)

@@ -8,6 +8,7 @@
 //   leaf_harness decompress <pack> <in.vqvdb>   <out.f32>   <batch>
 //   leaf_harness errors     <pack>
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
+//   leaf_harness makefile   <out.vqvdb> <n_leaves> (synthetic indices; config-3 input)
 #define VQVDB_HIP_STANDALONE
 #include <chrono>
 #include <cstdio>
@@ -112,6 +113,29 @@ int decompress(const std::string& pack, const std::string& in, const std::string
 	return 0;
 }
 
+// synthetic single-grid .vqvdb with pseudo-random indices (decode cost is data-independent): BASELINE config 3 input
+int makefile(const std::string& path, size_t total) {
+	vqvdb::StreamWriter w(path);
+	vqvdb::GridMeta m;
+	m.name = "density";
+	m.totalBlocks = total;
+	w.startGrid(m);
+	const size_t B = 65536;
+	std::vector<uint8_t> idx(B * 64);
+	std::vector<vqvdb::Coord3i> org(B);
+	uint32_t x = 2463534242u;
+	for (size_t s = 0; s < total; s += B) {
+		const size_t n = std::min(B, total - s);
+		for (size_t i = 0; i < n * 64; ++i) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; idx[i] = static_cast<uint8_t>(x >> 11); }
+		for (size_t i = 0; i < n; ++i) org[i] = originOf(s + i);
+		w.writeBatch(idx.data(), org.data(), n);
+	}
+	w.endGrid();
+	w.close();
+	std::printf("makefile: %zu leaves -> %s\n", total, path.c_str());
+	return 0;
+}
+
 // .vqvdb framing round trip without any backend (CPU-only test hook): two grids, ragged batches
 int streamtest(const std::string& path) {
 	std::vector<uint8_t> idx(1000 * 64);
@@ -193,6 +217,7 @@ int main(int argc, char** argv) {
 		if (mode == "decompress" && argc == 6) return decompress(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "errors" && argc == 3) return errors(argv[2]);
 		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
+		if (mode == "makefile" && argc == 4) return makefile(argv[2], std::stoul(argv[3]));
 		std::fprintf(stderr, "usage: leaf_harness compress|decompress|errors ...\n");
 		return 2;
 	} catch (const std::exception& e) {
