@@ -45,6 +45,9 @@ class Oracle:
             f.restype = ctypes.c_int
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                           ctypes.c_void_p, ctypes.c_int]
+        self.lib.vqo_decode_ex.restype = ctypes.c_int
+        self.lib.vqo_decode_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         self.lib.vqo_expf.restype = ctypes.c_float
         self.lib.vqo_expf.argtypes = [ctypes.c_float]
 
@@ -69,12 +72,14 @@ class Oracle:
             raise RuntimeError("oracle encode failed")
         return (idx, bufs) if debug else idx
 
-    def decode(self, idx: np.ndarray, threads: int = 1, debug=()):
+    def decode(self, idx: np.ndarray, threads: int = 1, debug=(), unfolded: bool = False):
+        """unfolded=True runs the decoder tail layer by layer (up_conv -> pixel shuffle -> final) instead
+        of the folded composite the GPU uses; both are restatements of VQVAE_v2.py:265-275."""
         idx = np.ascontiguousarray(idx, dtype=np.uint8).reshape(-1, 64)
         B = idx.shape[0]
         out = np.zeros((B, 512), dtype=np.float32)
         ptrs, bufs = self._dbg(B, set(debug))
-        rc = self.lib.vqo_decode(self._wptr, idx.ctypes.data, B, out.ctypes.data, ptrs, threads)
+        rc = self.lib.vqo_decode_ex(self._wptr, idx.ctypes.data, B, out.ctypes.data, ptrs, threads, int(unfolded))
         if rc:
             raise RuntimeError("oracle decode failed")
         return (out, bufs) if debug else out

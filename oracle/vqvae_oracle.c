@@ -227,7 +227,101 @@ static void conv_tapsum(const float* in, float* out, const float* W, const float
     }
 }
 
-/* final conv (Cout = 1, Cin = 32, k3 p1 @8^3): per-tap partial dot products summed over taps */
+/* ---- folded decoder tail -------------------------------------------------------------------
+ * up_conv (64->256,k3 @4^3) -> PixelShuffle3D(2) -> final (32->1,k3 @8^3) has no nonlinearity in
+ * between (VQVAE_v2.py:274-275), so it is ONE linear map 64ch@4^3 -> 1ch@8^3 whose weights depend on
+ * the output voxel (two levels of zero padding).  Contract for the composite weights (fp64, then
+ * rounded to fp32 once):
+ *   G[dl][s][t][ci] = sum_{oc asc} fma(Wf[oc][dl], Wu[oc*8+s][ci][t], .)       Bg[dl][s] likewise with b_up
+ *   Wc[ov][p][ci]   = sum over valid final taps dl ascending of G[dl][s'][t][ci], where the tap's 8^3
+ *                     neighbour z = ov + dl - 1 lies in 4^3 cell c' = z/2 with sub-position s' = z%2 and
+ *                     t is the up_conv tap with p = c' + t - 1                    (plain fp64 adds from 0)
+ *   bc[ov]          = b_final + sum over valid dl ascending of Bg[dl][s']
+ * Apply: per 128-voxel slab d (depths 2d,2d+1) the positions p = (pd,ph,pw), pd in [max(0,d-2),
+ * min(3,d+2)], are visited in ascending order (weights that are structurally zero are still
+ * multiplied: fmaf(0,x,acc)), channels in "P8" order; pre = acc + bc; out = sigmoid(pre). */
+typedef struct {
+    float* wc;  /* [512][64 pos][64 ci] */
+    float bc[512];
+} tail_t;
+
+static tail_t* tail_build(const float* Wu /*[256][64][27]*/, const float* bu, const float* Wf /*[1][32][27]*/, const float* bf)
+{
+    tail_t* T = (tail_t*)malloc(sizeof(tail_t));
+    double* G = (double*)malloc(sizeof(double) * 27 * 8 * 27 * 64);
+    double Bg[27][8];
+    double* acc = (double*)malloc(sizeof(double) * 64 * 64);
+    T->wc = (float*)malloc(sizeof(float) * 512 * 64 * 64);
+    for (int dl = 0; dl < 27; ++dl)
+        for (int s = 0; s < 8; ++s) {
+            double b = 0.0;
+            for (int oc = 0; oc < 32; ++oc) b = fma((double)Wf[oc * 27 + dl], (double)bu[oc * 8 + s], b);
+            Bg[dl][s] = b;
+            for (int t = 0; t < 27; ++t)
+                for (int ci = 0; ci < 64; ++ci) {
+                    double a = 0.0;
+                    for (int oc = 0; oc < 32; ++oc)
+                        a = fma((double)Wf[oc * 27 + dl], (double)Wu[((size_t)(oc * 8 + s) * 64 + ci) * 27 + t], a);
+                    G[(((size_t)dl * 8 + s) * 27 + t) * 64 + ci] = a;
+                }
+        }
+    for (int od = 0; od < 8; ++od)
+    for (int oh = 0; oh < 8; ++oh)
+    for (int ow = 0; ow < 8; ++ow) {
+        const int ov = (od * 8 + oh) * 8 + ow;
+        double b = (double)bf[0];
+        for (int i = 0; i < 64 * 64; ++i) acc[i] = 0.0;
+        for (int dd = 0; dd < 3; ++dd)
+        for (int dh = 0; dh < 3; ++dh)
+        for (int dw = 0; dw < 3; ++dw) {
+            const int zd = od + dd - 1, zh = oh + dh - 1, zw = ow + dw - 1;
+            if (zd < 0 || zd > 7 || zh < 0 || zh > 7 || zw < 0 || zw > 7) continue;
+            const int dl = (dd * 3 + dh) * 3 + dw;
+            const int cd = zd >> 1, ch = zh >> 1, cw = zw >> 1, s = (zd & 1) * 4 + (zh & 1) * 2 + (zw & 1);
+            b = b + Bg[dl][s];
+            for (int td = 0; td < 3; ++td)
+            for (int th = 0; th < 3; ++th)
+            for (int tw = 0; tw < 3; ++tw) {
+                const int pd = cd + td - 1, ph = ch + th - 1, pw = cw + tw - 1;
+                if (pd < 0 || pd > 3 || ph < 0 || ph > 3 || pw < 0 || pw > 3) continue;
+                const double* g = G + (((size_t)dl * 8 + s) * 27 + (td * 3 + th) * 3 + tw) * 64;
+                double* a = acc + (size_t)((pd * 4 + ph) * 4 + pw) * 64;
+                for (int ci = 0; ci < 64; ++ci) a[ci] = a[ci] + g[ci];
+            }
+        }
+        T->bc[ov] = (float)b;
+        for (int i = 0; i < 64 * 64; ++i) T->wc[(size_t)ov * 4096 + i] = (float)acc[i];
+    }
+    free(G);
+    free(acc);
+    return T;
+}
+static void tail_free(tail_t* T) { if (T) { free(T->wc); free(T); } }
+
+static void tail_apply(const tail_t* T, const float* in /*[64][64][LT]*/, float* pre /*[512][LT]*/)
+{
+    int p8[64];
+    korder_p8(64, p8);
+    for (int ov = 0; ov < 512; ++ov) {
+        const int d = ov >> 7;
+        const int pd0 = d - 2 < 0 ? 0 : d - 2, pd1 = d + 2 > 3 ? 3 : d + 2;
+        float acc[LT];
+        for (int l = 0; l < LT; ++l) acc[l] = 0.0f;
+        for (int p = pd0 * 16; p < (pd1 + 1) * 16; ++p) {
+            const float* w = T->wc + (size_t)ov * 4096 + (size_t)p * 64;
+            for (int cc = 0; cc < 64; ++cc) {
+                const int ci = p8[cc];
+                const float wv = w[ci];
+                const float* x = in + ((size_t)ci * 64 + p) * LT;
+                for (int l = 0; l < LT; ++l) acc[l] = fmaf(wv, x[l], acc[l]);
+            }
+        }
+        for (int l = 0; l < LT; ++l) pre[(size_t)ov * LT + l] = acc[l] + T->bc[ov];
+    }
+}
+
+/* final conv (Cout = 1, Cin = 32, k3 p1 @8^3): per-tap partial dot products summed over taps
+ * (unfolded form; kept for cross-checking the folded tail in the CPU tests) */
 static void conv_final(const float* in /*[32][512][LT]*/, float* out /*[512][LT]*/, const float* W /*[1][32][27]*/, const float* bias)
 {
     int p8[32];
@@ -461,7 +555,7 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
 }
 
 static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0, int nl, float* out,
-                        float* const* dbg, scratch_t* s)
+                        float* const* dbg, scratch_t* s, const tail_t* tail, int unfolded)
 {
     int p8_64[64], p8_128[128];
     korder_p8(64, p8_64); korder_p8(128, p8_128);
@@ -490,21 +584,25 @@ static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0
     float* x7 = s->a;
     channel_attention(x6, x7, 64, W[W_D_FC0], W[W_D_FC2]);
     if (dbg) dump(dbg[DBG_D_X7], x7, 64, 64, leaf0, nl);
-    float* up = s->b; /* [256][64][LT] */
-    conv3d(x7, up, W[W_D_UP_W], W[W_D_UP_B], 64, 256, 4, 4, 3, 1, 1, p8_64);
-    if (dbg) dump(dbg[DBG_D_UP], up, 256, 64, leaf0, nl);
-    /* PixelShuffle3D(2) (VQVAE_v2.py:172-187): out[oc][2d+i][2h+j][2w+k] = in[oc*8+i*4+j*2+k][d][h][w] */
-    float* ps = s->c; /* [32][512][LT] */
-    for (int oc = 0; oc < 32; ++oc)
-        for (int d = 0; d < 4; ++d) for (int h = 0; h < 4; ++h) for (int w = 0; w < 4; ++w)
-            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
-                const int ci = oc * 8 + i * 4 + j * 2 + k;
-                const int po = ((2 * d + i) * 8 + (2 * h + j)) * 8 + (2 * w + k);
-                memcpy(ps + ((size_t)oc * 512 + po) * LT, up + ((size_t)ci * 64 + (d * 4 + h) * 4 + w) * LT, sizeof(float) * LT);
-            }
-    if (dbg) dump(dbg[DBG_D_PS], ps, 32, 512, leaf0, nl);
     float* pre = s->d; /* [1][512][LT] */
-    conv_final(ps, pre, W[W_D_FINAL_W], W[W_D_FINAL_B]);
+    if (!unfolded) {
+        tail_apply(tail, x7, pre);
+    } else {
+        float* up = s->b; /* [256][64][LT] */
+        conv3d(x7, up, W[W_D_UP_W], W[W_D_UP_B], 64, 256, 4, 4, 3, 1, 1, p8_64);
+        if (dbg) dump(dbg[DBG_D_UP], up, 256, 64, leaf0, nl);
+        /* PixelShuffle3D(2) (VQVAE_v2.py:172-187): out[oc][2d+i][2h+j][2w+k] = in[oc*8+i*4+j*2+k][d][h][w] */
+        float* ps = s->c; /* [32][512][LT] */
+        for (int oc = 0; oc < 32; ++oc)
+            for (int d = 0; d < 4; ++d) for (int h = 0; h < 4; ++h) for (int w = 0; w < 4; ++w)
+                for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+                    const int ci = oc * 8 + i * 4 + j * 2 + k;
+                    const int po = ((2 * d + i) * 8 + (2 * h + j)) * 8 + (2 * w + k);
+                    memcpy(ps + ((size_t)oc * 512 + po) * LT, up + ((size_t)ci * 64 + (d * 4 + h) * 4 + w) * LT, sizeof(float) * LT);
+                }
+        if (dbg) dump(dbg[DBG_D_PS], ps, 32, 512, leaf0, nl);
+        conv_final(ps, pre, W[W_D_FINAL_W], W[W_D_FINAL_B]);
+    }
     if (dbg) dump(dbg[DBG_D_PRE], pre, 1, 512, leaf0, nl);
     for (int p = 0; p < 512; ++p)
         for (int l = 0; l < nl; ++l) out[(size_t)(leaf0 + l) * 512 + p] = vq_sigmoid(pre[p * LT + l]);
@@ -555,9 +653,18 @@ int vqo_encode(const float* const* W, const float* leaves, int64_t B, uint8_t* i
     return err;
 }
 
+/* unfolded != 0: run the decoder tail layer by layer (up_conv, pixel shuffle, final) instead of folded */
+int vqo_decode_ex(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads, int unfolded);
+
 int vqo_decode(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads)
 {
+    return vqo_decode_ex(W, idx, B, out, dbg, nthreads, 0);
+}
+
+int vqo_decode_ex(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads, int unfolded)
+{
     if (B <= 0) return 0;
+    tail_t* tail = unfolded ? NULL : tail_build(W[W_D_UP_W], W[W_D_UP_B], W[W_D_FINAL_W], W[W_D_FINAL_B]);
     const int64_t ntiles = (B + LT - 1) / LT;
     int err = 0;
     if (nthreads < 1) nthreads = 1;
@@ -571,10 +678,11 @@ int vqo_decode(const float* const* W, const uint8_t* idx, int64_t B, float* out,
 #pragma omp for schedule(dynamic, 1)
             for (int64_t t = 0; t < ntiles; ++t) {
                 const int nl = (int)((B - t * LT) < LT ? (B - t * LT) : LT);
-                decode_tile(W, idx, t * LT, nl, out, dbg, &s);
+                decode_tile(W, idx, t * LT, nl, out, dbg, &s, tail, unfolded);
             }
         }
         scratch_free(&s);
     }
+    tail_free(tail);
     return err;
 }

@@ -50,7 +50,7 @@ def main():
     rec = codec.decode(oidx)
     print(f"decode {n} leaves: {time.time() - t:.3f}s", flush=True)
     orec, ddbg = orc.decode(oidx, threads=8, debug=DEC_DEBUG)
-    for name in ["d_ystem", "d_d2", "d_y4", "d_x6", "d_ps"]:
+    for name in ["d_ystem", "d_d2", "d_y4", "d_x6"]:
         c, p = DEBUG_SHAPES[name]
         cmp(name, codec.debug_fetch(name, n, c, p), ddbg[name])
     cmp("recon", rec, orec)

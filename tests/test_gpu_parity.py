@@ -56,7 +56,7 @@ def test_decode_bit_exact_vs_oracle_all_layers(codec, oracle, golden):
     idx = np.concatenate([golden["idx_rand"][:100], golden["idx_edge"]])
     rec = codec.decode(idx)
     orec, dbg = oracle.decode(idx, threads=8, debug=DEC_DEBUG)
-    for name in ["d_ystem", "d_d2", "d_y4", "d_x6", "d_ps"]:
+    for name in ["d_ystem", "d_d2", "d_y4", "d_x6"]:
         c, p = DEBUG_SHAPES[name]
         assert np.array_equal(_bits(codec.debug_fetch(name, len(idx), c, p)), _bits(dbg[name])), name
     assert np.array_equal(_bits(rec), _bits(orec))

@@ -15,7 +15,8 @@ TOL = 1e-5
 ENC_MAP = {"e_y1": "act_enc_pre0", "e_a1": "act_enc_pre2", "e_a6": "act_enc_pre3", "e_x7": "act_enc_down",
            "e_x11": "act_enc_res", "e_x12": "act_enc_attn", "e_z": "act_enc_proj"}
 DEC_MAP = {"d_ystem": "act_dec_stem0", "d_d2": "act_dec_stem", "d_x6": "act_dec_res", "d_x7": "act_dec_attn",
-           "d_up": "act_dec_up", "d_ps": "act_dec_ps", "d_pre": "act_dec_final"}
+           "d_pre": "act_dec_final"}            # folded tail: up_conv / pixel-shuffle outputs are never formed
+DEC_MAP_UNFOLDED = {"d_up": "act_dec_up", "d_ps": "act_dec_ps", "d_pre": "act_dec_final"}
 
 
 def _check_indices(got, want, golden, flat_offset):
@@ -60,6 +61,17 @@ def test_decode_matches_reference(oracle, golden):
     assert float((np.abs(rec - want) / np.abs(want)).max()) < TOL      # element-wise relative
     rec_e = oracle.decode(golden["idx_edge"], threads=4)
     assert float((np.abs(rec_e - golden["rec_edge"]) / np.abs(golden["rec_edge"])).max()) < TOL
+
+
+def test_unfolded_decoder_tail_matches_reference_and_folded(oracle, golden):
+    """The layer-by-layer tail (up_conv -> PixelShuffle3D -> final) pins the intermediate tensors to the
+    reference; the folded composite the GPU runs must agree with it to fp32 round-off."""
+    rec_u, dbg = oracle.decode(golden["idx_rand"][:16], threads=8, debug=DEC_DEBUG, unfolded=True)
+    for ours, ref in DEC_MAP_UNFOLDED.items():
+        assert rel_err(dbg[ours][0], golden[ref]) < TOL, ours
+    rec_f = oracle.decode(golden["idx_rand"][:16], threads=8)
+    assert float((np.abs(rec_u - golden["rec_rand"][:16]) / np.abs(golden["rec_rand"][:16])).max()) < TOL
+    assert float((np.abs(rec_f - rec_u) / np.abs(rec_u)).max()) < TOL
 
 
 def test_batch_and_thread_independence(oracle):

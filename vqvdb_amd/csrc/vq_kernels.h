@@ -29,7 +29,7 @@ struct ConvArgs {
     float* out_csum;         // [tile][COUT][32]
     int n_steps;             // length of the flattened (output, valid taps) schedule passed beside ConvArgs
     int n_taps;
-    int mt_base;             // PIXSHUF only: first 32-cout tile handled by this launch (cout split over launches)
+    int64_t n_leaves;        // OUTMODE 2 only: leaves that really exist (the last tile may be padded)
     int n_tiles;
 };
 
@@ -399,10 +399,13 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
 //   INMODE 0: raw input      1: relu(GroupNorm(GIN)) on load      2: squeeze-excite gate on load
 //   RESID  : out = skip + 0.1*(acc+bias)        GOUT: GroupNorm statistics of the output
 //   CSUM   : per-channel sums of the output (feeds ChannelAttention of the next kernel)
-//   PIXSHUF: store through PixelShuffle3D(2) (VQVAE_v2.py:172-187) into a 32-channel 8^3 tensor
+//   OUTMODE 0: store the leaf-tile activation.  2: folded decoder tail — the "positions" are the four
+//            128-voxel output slabs, the "taps" the input positions of the slab's receptive field, the
+//            rows of the weight fragments output VOXELS; epilogue = per-voxel bias, sigmoid, store into
+//            the caller's leaf-major [n][512] buffer (VQVAECodec.cpp:182-192).
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int NPI, int NPO, int NW, bool STREAM, int KWG, int INMODE, int GIN, bool RESID, int GOUT,
-          bool CSUM, bool PIXSHUF>
+          bool CSUM, int OUTMODE>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
         for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bias = bf4[(mt * 2 + q) * 4 + g];
+                const f32x4 bias = bf4[((OUTMODE == 2 ? po * NMT : 0) + mt) * 8 + q * 4 + g];
                 f32x4 v;
                 v.x = acc[mt][4 * g + 0] + bias.x;
                 v.y = acc[mt][4 * g + 1] + bias.y;
@@ -576,7 +579,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     const f32x4 u = v * 0.1f;
                     v = skv[mt][g] + u;
                 }
-                if (!PIXSHUF && active) ((f32x4*)A.out)[o] = v;
+                if (OUTMODE == 0 && active) ((f32x4*)A.out)[o] = v;
+                if (OUTMODE == 2) {
+                    // rows 32mt + 8g + 4q + {0..3} of slab po are 4 consecutive voxels of this lane's leaf
+                    const int64_t leaf = (int64_t)tile * 32 + j;
+                    if (active && leaf < A.n_leaves) {
+                        f32x4 sg;
+                        sg.x = vq_sigmoid(v.x), sg.y = vq_sigmoid(v.y), sg.z = vq_sigmoid(v.z), sg.w = vq_sigmoid(v.w);
+                        *(f32x4*)(A.out + leaf * 512 + po * 128 + 32 * mt + 8 * g + 4 * q) = sg;
+                    }
+                }
                 if (GOUT > 0) {
                     st[mt * 4 + g].add(v.x);
                     st[mt * 4 + g].add(v.y);
@@ -588,22 +600,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     cs[mt][4 * g + 1] = cs[mt][4 * g + 1] + v.y;
                     cs[mt][4 * g + 2] = cs[mt][4 * g + 2] + v.z;
                     cs[mt][4 * g + 3] = cs[mt][4 * g + 3] + v.w;
-                }
-                if (PIXSHUF) acc[mt][4 * g + 0] = v.x, acc[mt][4 * g + 1] = v.y, acc[mt][4 * g + 2] = v.z, acc[mt][4 * g + 3] = v.w;
-            }
-            if (PIXSHUF && active) {
-                // cout = 32mt + 8g + 4q + i  ->  oc = cout/8 = 4mt + g, sub = cout%8 = 4q + i
-                // out[oc][2d+q][2h+(i>>1)][2w+(i&1)]; the 4 g's form L4 group mt of the 32-ch tensor.
-                const int od = po >> 4, oh = (po >> 2) & 3, ow = po & 3;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int p8 = ((2 * od + q) * 8 + 2 * oh + (i >> 1)) * 8 + 2 * ow + (i & 1);
-                    f32x4 v;
-                    v.x = acc[mt][i];
-                    v.y = acc[mt][4 + i];
-                    v.z = acc[mt][8 + i];
-                    v.w = acc[mt][12 + i];
-                    ((f32x4*)A.out)[(((size_t)tile * 512 + p8) * 8 + A.mt_base + mt) * 32 + j] = v;
                 }
             }
         }
@@ -869,106 +865,6 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
         gn_finish(st[2 * k].s + st[2 * k + 1].s, st[2 * k].q + st[2 * k + 1].q, 1.0 / 512.0, m, r);
         out_mean[((size_t)tile * 8 + h * 4 + k) * 32 + j] = m;
         out_rstd[((size_t)tile * 8 + h * 4 + k) * 32 + j] = r;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// D10/D11: Conv3d(32->1,k3,p1) @8^3 + sigmoid (VQVAE_v2.py:268,275), output leaf-major
-// [n][512] as the orchestrator's unpack loop expects (VQVAECodec.cpp:182-192).
-// One output channel has no GEMM N dimension, so the matrix shape is built from the TAPS:
-// input-stationary, per input position one MFMA block  P[tap(27 of 32 rows)][leaf] =
-// sum_cin W[tap][cin] * x[cin][leaf]  (16 x 32x32x2 MFMAs, K order P8), then each lane
-// scatter-adds its 16 tap partials into the outputs they belong to (out[pos - off(tap)]), which
-// live in a 3-slab (od ring) LDS accumulator per wave.  The 64 KB/leaf input is read exactly
-// once; an output slab is finished (bias, sigmoid, coalesced store) as soon as the input slab
-// after it has been consumed.  Accumulation order per output: valid taps ascending, each tap a
-// cin-chain from 0 (restated by the oracle's final conv).
-// ------------------------------------------------------------------------------------------
-constexpr int FIN_SLAB = 64 * 33;          // floats per output slab (64 positions x (32 leaves + 1 pad))
-constexpr int FIN_LDS_WAVE = 3 * FIN_SLAB; // floats per wave
-
-__global__ __launch_bounds__(256) void final_mfma_k(const float* __restrict__ ps, const float* __restrict__ wfrag, float bias,
-                                                    float* __restrict__ out, int64_t n_leaves, int n_tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= n_tiles) return;  // no workgroup barriers below: waves are independent
-    float* ring = (float*)smem_raw + wave * FIN_LDS_WAVE;
-    const int j = lane & 31, q = lane >> 5;
-    for (int i = lane; i < FIN_LDS_WAVE; i += 64) ring[i] = 0.0f;
-
-    // per-lane constants of the 16 taps this lane's accumulator registers hold
-    unsigned vmask[16];  // valid input coordinates per axis: bits 16..23 id, 8..15 ih, 0..7 iw
-    int poff[16];        // (kh-1)*8 + (kw-1)
-    int kdr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = (r & 3) + 8 * (r >> 2) + 4 * q;
-        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
-        const unsigned md = kd == 0 ? 0x7Fu : (kd == 1 ? 0xFFu : 0xFEu);
-        const unsigned mh = kh == 0 ? 0x7Fu : (kh == 1 ? 0xFFu : 0xFEu);
-        const unsigned mw = kw == 0 ? 0x7Fu : (kw == 1 ? 0xFFu : 0xFEu);
-        vmask[r] = t < 27 ? (md << 16) | (mh << 8) | mw : 0u;
-        poff[r] = (kh - 1) * 8 + (kw - 1);
-        kdr[r] = kd;
-    }
-    f32x4 wa[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wa[u] = ((const f32x4*)wfrag)[u * 64 + lane];
-    const f32x4* in4 = (const f32x4*)ps + (size_t)tile * 512 * 8 * 32 + q * 32 + j;
-    f32x4 bn[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bn[u] = in4[u * 64];
-
-    for (int id = 0; id < 8; ++id) {
-        for (int p = 0; p < 64; ++p) {
-            f32x4 bc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bc[u] = bn[u];
-            const int pn = min(id * 64 + p + 1, 511);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bn[u] = in4[(size_t)pn * 8 * 32 + u * 64];
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = mfma32(wa[u].x, bc[u].x, acc);
-                acc = mfma32(wa[u].y, bc[u].y, acc);
-                acc = mfma32(wa[u].z, bc[u].z, acc);
-                acc = mfma32(wa[u].w, bc[u].w, acc);
-            }
-            // scatter-add the tap partials: out(od,oh,ow) with od = id+1-kd, (oh,ow) = p - poff
-            const int ih = p >> 3, iw = p & 7;
-            float old[16];
-            int addr[16];
-            bool ok[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                ok[r] = ((vmask[r] >> (16 + id)) & (vmask[r] >> (8 + ih)) & (vmask[r] >> iw) & 1u) != 0;
-                const int od = id + 1 - kdr[r];
-                const int slot = od - 3 * ((od * 11) >> 5);  // od % 3 for od in [0,8)
-                addr[r] = ok[r] ? (slot * 64 + p - poff[r]) * 33 + j : 0;
-                old[r] = ok[r] ? ring[addr[r]] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok[r]) ring[addr[r]] = old[r] + acc[r];
-        }
-        // output slabs whose last contributing input slab is `id`: od = id-1, and od = 7 at the end
-#pragma unroll 1
-        for (int od = (id >= 1 ? id - 1 : 8); od <= (id == 7 ? 7 : id - 1); ++od) {
-            const int slot = od % 3;
-            for (int l = 0; l < 32; ++l) {
-                const int a = (slot * 64 + lane) * 33 + l;
-                const float v = ring[a];
-                ring[a] = 0.0f;
-                const int64_t leaf = (int64_t)tile * 32 + l;
-                if (leaf < n_leaves) out[leaf * 512 + od * 64 + lane] = vq_sigmoid(v + bias);
-            }
-        }
     }
 }
 

@@ -51,8 +51,9 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"dec_stem", {0.0, 0.0}},  // table lookups: the 14.2 M MAC/leaf of the reference op are not executed (stem_lut_k)
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
-        {"dec_up_conv", {28311552.0 + 2048, 28311552.0 * 0.578704 + 2048}},  // per launch: half of the 256 couts
-        {"dec_final", {2.0 * 442368, 2.0 * 442368 * 0.7703}},  // algorithmic; the kernel issues 512*32*32 MACs/leaf as MFMA
+        // folded up_conv+pixshuf+final: nominal = the reference ops' dense count; "effective" = the MACs the
+        // folded map really needs (884 736/leaf); the kernel issues 224 steps x 128 x 64 = 1 835 008 MAC/leaf
+        {"dec_tail", {2.0 * (28311552 + 2048 + 442368), 2.0 * 884736}},
     };
     return m;
 }
@@ -280,6 +281,80 @@ int upload(vqhip_codec* c, const char* name, const PackTensor* t)
     return upload(c, name, std::vector<float>(t->data, t->data + t->count));
 }
 
+// Folded decoder tail: up_conv (64->256,k3 @4^3) -> PixelShuffle3D(2) -> final (32->1,k3 @8^3) is one
+// linear map (no nonlinearity in between, VQVAE_v2.py:274-275).  Composite weights per output voxel,
+// built in fp64 in the contract's order (see oracle tail_build) and rounded to fp32 once; laid out as
+// MFMA A-fragments per (output slab d, input position p) with the 128 voxels of the slab as rows.
+int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const float* Wf, const float* bf)
+{
+    std::vector<double> G((size_t)27 * 8 * 27 * 64);
+    double Bg[27][8];
+    for (int dl = 0; dl < 27; ++dl)
+        for (int sb = 0; sb < 8; ++sb) {
+            double b = 0.0;
+            for (int oc = 0; oc < 32; ++oc) b = __builtin_fma((double)Wf[oc * 27 + dl], (double)bu[oc * 8 + sb], b);
+            Bg[dl][sb] = b;
+            for (int t = 0; t < 27; ++t)
+                for (int ci = 0; ci < 64; ++ci) {
+                    double a = 0.0;
+                    for (int oc = 0; oc < 32; ++oc)
+                        a = __builtin_fma((double)Wf[oc * 27 + dl], (double)Wu[((size_t)(oc * 8 + sb) * 64 + ci) * 27 + t], a);
+                    G[(((size_t)dl * 8 + sb) * 27 + t) * 64 + ci] = a;
+                }
+        }
+    std::vector<float> wc((size_t)512 * 64 * 64), bc(512);
+    std::vector<double> acc(64 * 64);
+    for (int od = 0; od < 8; ++od)
+        for (int oh = 0; oh < 8; ++oh)
+            for (int ow = 0; ow < 8; ++ow) {
+                const int ov = (od * 8 + oh) * 8 + ow;
+                double b = (double)bf[0];
+                std::fill(acc.begin(), acc.end(), 0.0);
+                for (int dd = 0; dd < 3; ++dd)
+                    for (int dh = 0; dh < 3; ++dh)
+                        for (int dw = 0; dw < 3; ++dw) {
+                            const int zd = od + dd - 1, zh = oh + dh - 1, zw = ow + dw - 1;
+                            if (zd < 0 || zd > 7 || zh < 0 || zh > 7 || zw < 0 || zw > 7) continue;
+                            const int dl = (dd * 3 + dh) * 3 + dw;
+                            const int cd = zd >> 1, ch = zh >> 1, cw = zw >> 1, sb = (zd & 1) * 4 + (zh & 1) * 2 + (zw & 1);
+                            b = b + Bg[dl][sb];
+                            for (int td = 0; td < 3; ++td)
+                                for (int th = 0; th < 3; ++th)
+                                    for (int tw = 0; tw < 3; ++tw) {
+                                        const int pd = cd + td - 1, ph = ch + th - 1, pw = cw + tw - 1;
+                                        if (pd < 0 || pd > 3 || ph < 0 || ph > 3 || pw < 0 || pw > 3) continue;
+                                        const double* g = &G[(((size_t)dl * 8 + sb) * 27 + (td * 3 + th) * 3 + tw) * 64];
+                                        double* a = &acc[(size_t)((pd * 4 + ph) * 4 + pw) * 64];
+                                        for (int ci = 0; ci < 64; ++ci) a[ci] = a[ci] + g[ci];
+                                    }
+                        }
+                bc[ov] = (float)b;
+                for (int i = 0; i < 64 * 64; ++i) wc[(size_t)ov * 4096 + i] = (float)acc[i];
+            }
+    // fragments + schedule: slab d visits positions pd in [max(0,d-2), min(3,d+2)] x all (ph,pw), ascending
+    std::vector<float> frags, bias;
+    std::vector<int> steps;
+    std::vector<float> wslab((size_t)128 * 64);
+    for (int d = 0; d < 4; ++d) {
+        const size_t first = steps.size();
+        for (int p = std::max(0, d - 2) * 16; p < (std::min(3, d + 2) + 1) * 16; ++p) {
+            for (int row = 0; row < 128; ++row)
+                for (int ci = 0; ci < 64; ++ci) wslab[(size_t)row * 64 + ci] = wc[((size_t)(d * 128 + row) * 64 + p) * 64 + ci];
+            const std::vector<float> f = frag32(wslab.data(), 128, 64, 1);
+            steps.insert(steps.end(), {p, (int)(frags.size() / f.size()), d, 1 << 8});
+            frags.insert(frags.end(), f.begin(), f.end());
+        }
+        steps[first + 3] |= 1;
+        steps[steps.size() - 1] |= 2;
+        const std::vector<float> bfrag = dfrag32(bc.data() + d * 128, 128);
+        bias.insert(bias.end(), bfrag.begin(), bfrag.end());
+    }
+    int rc;
+    if ((rc = upload(c, "tail.w", frags))) return rc;
+    if ((rc = upload(c, "tail.b", bias))) return rc;
+    return upload_i(c, "steps.tail", steps);
+}
+
 int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
 {
     std::string err;
@@ -323,16 +398,7 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ds.w", dsw) UP("ds.b", dsb) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
     UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
-    UP("dfc0", dfc0) UP("dfc2", dfc2) UP("du.w0", frag32(duw->data, 128, 64, 27)) UP("du.w1", frag32(duw->data + (size_t)128 * 64 * 27, 128, 64, 27))
-    UP("du.b0", dfrag32(dub->data, 128)) UP("du.b1", dfrag32(dub->data + 128, 128))
-    {
-        // final conv as a [32 taps (27 real) x 32 cin] matrix: rows = taps -> A fragments of one 32x32 tile
-        std::vector<float> wt(32 * 32, 0.0f);  // [tap][cin][1]
-        for (int t = 0; t < 27; ++t)
-            for (int ci = 0; ci < 32; ++ci) wt[t * 32 + ci] = dfw->data[ci * 27 + t];
-        UP("df.w", frag32(wt.data(), 32, 32, 1))
-        c->e_final_bias = dfb->data[0];
-    }
+    UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
     UP("cb", cb) UP("cb.frag", frag32(cb->data, 256, 128, 1))
     {
         // ||e_k||^2: fmaf chain over ascending c (arithmetic contract, oracle vqo_code_norms)
@@ -369,7 +435,7 @@ struct ActSpec {
 const ActSpec kActs[] = {
     {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
     {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},    {"e_z", 128, 64},
-    {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},   {"d_ps", 32, 512},
+    {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},
     {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64},
 };
 
@@ -442,18 +508,17 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 }
 
 // kernel instantiations -------------------------------------------------------------------
-//                                          CIN COUT NPI NPO NW STREAM KWG INMODE GIN RESID GOUT CSUM  PIXSHUF
-constexpr auto k_enc_down = conv_mfma32_k<16, 32, 512, 64, 8, false, 4, 0, 0, false, 8, false, false>;
-constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false, 8, false, false>;
-constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true, 0, true, false>;
-constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false, 8, false, false>;
-constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true, 0, true, false>;
-constexpr auto k_dec_up = conv_mfma32_k<64, 128, 64, 64, 8, true, 1, 2, 0, false, 0, false, true>;  // launched twice (cout halves)
+//                                          CIN COUT NPI NPO NW STREAM KWG INMODE GIN RESID GOUT CSUM  OUTMODE
+constexpr auto k_enc_down = conv_mfma32_k<16, 32, 512, 64, 8, false, 4, 0, 0, false, 8, false, 0>;
+constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false, 8, false, 0>;
+constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true, 0, true, 0>;
+constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false, 8, false, 0>;
+constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true, 0, true, 0>;
+constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
 constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
-constexpr size_t LDS_DEC_UP = (size_t)2 * (8 * 4 * 64) * 16;      // 2 x 32 KB
-constexpr size_t LDS_DEC_FINAL = (size_t)4 * FIN_LDS_WAVE * sizeof(float);  // 99 KB: 4 waves x 3-slab output ring
+constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 constexpr size_t LDS_PROJ_VQ = (size_t)(16 * 8 * 64 + 4 * 4 * 64) * 16;  // 144 KB
 
 int init_kernel_attrs(vqhip_codec* c)
@@ -463,7 +528,6 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, proj_vq_k<8>, LDS_PROJ_VQ))) return rc;
-    if ((rc = set_lds(c, final_mfma_k, LDS_DEC_FINAL))) return rc;
     return VQHIP_OK;
 }
 
@@ -577,17 +641,11 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     }
     {
         ConvArgs A{};
-        A.in = a["d_x6"], A.out = a["d_ps"];
-        A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
-        for (int half = 0; half < 2; ++half) {  // 256 couts as two 128-cout launches (register budget)
-            A.wfrag = w[half ? "du.w1" : "du.w0"], A.bias_frag = w[half ? "du.b1" : "du.b0"], A.mt_base = 4 * half;
-            L.run("dec_up_conv", [&] { hipLaunchKernelGGL(k_dec_up, dim3(g8), dim3(512), LDS_DEC_UP, s, A, (const int4*)w["steps.k3s1_4"]); });
-        }
+        A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
+        A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
+        A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0;
+        L.run("dec_tail", [&] { hipLaunchKernelGGL(k_dec_tail, dim3(g8), dim3(512), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
     }
-    L.run("dec_final", [&] {
-        hipLaunchKernelGGL(final_mfma_k, dim3(g4), dim3(256), LDS_DEC_FINAL, s, a["d_ps"], w["df.w"], c->e_final_bias, d_out, n, nt);
-    });
     return L.rc;
 }
 
