@@ -76,9 +76,23 @@ def roofline_of(kernels, total_flop_per_leaf, leaves_per_s_per_gpu):
         "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": None,
         "achieved_effective": dom["tflops_effective"], "avg_launch_ms": dom["avg_ms"],
         "whole_path_frac": round(leaves_per_s_per_gpu * total_flop_per_leaf / (PEAK_TF * 1e12), 4),
-        "note": "achieved = nominal dense FLOP per leaf of this kernel (padding taps counted) x 65536 leaves / avg launch time; "
-                "the kernel skips zero-padding taps, so nominal can exceed the MFMA peak; *_effective excludes them",
+        "note": "achieved = nominal dense FLOP per leaf of the reference ops this kernel replaces (SURVEY App. A, padding taps counted) "
+                "x 65536 leaves / avg launch time; the kernels skip zero-padding taps (and fold/look up linear operators), so nominal can "
+                "exceed the MFMA peak; achieved_effective = FLOPs really issued on the matrix pipe / time (true utilisation); "
+                "whole_path_frac = leaves/s x nominal FLOP per leaf of the whole path / peak",
     }
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline():
@@ -87,7 +101,7 @@ def cpu_baseline():
     from oracle.oracle import Oracle
     W = synth.make_weights(0)
     orc = Oracle(W, [t[0] for t in synth.TENSORS])
-    threads = os.cpu_count() or 1
+    threads = usable_cpus()
     n = max(1024, min(16384, 64 * threads))
     leaves = synth.make_leaves(n, seed=1234)
 
@@ -103,7 +117,8 @@ def cpu_baseline():
     _, dr, td = leg(orc.decode, idx)
     return {"value": round(n * er / te, 1), "unit": "leaves/s", "cores": threads, "kind": "port",
             "sample": f"{er} x {n} uniform-random leaves encode+quantize ({te:.1f} s) and {dr} x {n} decode ({td:.1f} s); "
-                      f"C oracle, OpenMP over 16-leaf tiles, {threads} threads",
+                      f"C oracle, OpenMP over 16-leaf tiles, {threads} threads "
+                      f"(= usable CPUs: affinity {len(os.sched_getaffinity(0))}, cgroup quota applied; {os.cpu_count()} visible)",
             "decode_value": round(n * dr / td, 1)}, (leaves, idx)
 
 
@@ -172,7 +187,7 @@ def main():
             enc(0)
             torch.cuda.synchronize(device)
             gi = idx[0][:64].cpu().numpy()
-            oi = orc.encode(h, threads=os.cpu_count() or 1)
+            oi = orc.encode(h, threads=usable_cpus())
             parity = f"{int((gi == oi).all(axis=1).sum())}/64 sampled leaves index-exact vs CPU oracle"
         host = None
         if args.host_path:

@@ -87,8 +87,8 @@ typedef struct vqhip_kernel_stat {
     char name[48];
     int64_t launches;
     double total_ms;
-    double flops_per_leaf;     /* nominal dense FLOPs this kernel performs per leaf (0 for data-movement kernels) */
-    double eff_flops_per_leaf; /* same, zero-padding taps excluded */
+    double flops_per_leaf;     /* nominal dense FLOPs per leaf of the reference ops this kernel replaces (0: data movement / table lookups) */
+    double eff_flops_per_leaf; /* FLOPs per leaf the kernel really issues (padding taps skipped, folded operators at folded cost) */
     int64_t leaves;            /* leaves processed over the counted launches */
 } vqhip_kernel_stat;
 int vqhip_profile_enable(vqhip_codec* codec, int enable);
@@ -97,7 +97,7 @@ int vqhip_profile_read(vqhip_codec* codec, vqhip_kernel_stat* stats, int cap, in
 /* Test hooks.  vqhip_debug_enable(1) makes encode also keep the 128-channel latent (it is
  * otherwise never written to memory).  vqhip_debug_fetch copies an intermediate activation
  * of the LAST encode/decode chunk to host as float32 [n_leaves][C][positions] (NCDHW
- * flattened).  Names: e_y1 e_a1 e_y4 e_a6 e_x7 e_y9 e_x11 e_z d_q d_ystem d_d2 d_y4 d_x6 d_ps. */
+ * flattened).  Names: e_y1 e_a1 e_y4 e_a6 e_x7 e_y9 e_x11 e_z d_ystem d_d2 d_y4 d_x6. */
 int vqhip_debug_enable(vqhip_codec* codec, int enable);
 int vqhip_debug_fetch(vqhip_codec* codec, const char* name, int64_t n_leaves, float* out);
 
