@@ -131,10 +131,17 @@ def main():
     ap.add_argument("--host-path", action="store_true", help="also time the host-pointer C ABI (pageable memory in/out, PCIe included)")
     args = ap.parse_args()
 
+    # Only the final JSON line may reach stdout.  Native libraries (RCCL prints its version banner with
+    # NCCL_DEBUG=VERSION, which this image exports) write to fd 1 directly, so fd 1 is pointed at stderr
+    # for the whole run and the JSON goes to a saved duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    dist = world > 1 or os.environ.get("VQ_BENCH_FORCE_DIST") == "1"   # the latter exercises the RCCL path with one rank
     if dist:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif args.gpus != 1:
@@ -218,7 +225,7 @@ def main():
             "parity_sample": parity,
             "host_path": host,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
