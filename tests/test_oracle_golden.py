@@ -88,3 +88,13 @@ def test_expf_polynomial_accuracy(oracle):
     xs = np.linspace(-30, 30, 2001)
     got = np.array([oracle.expf(float(x)) for x in xs])
     assert np.max(np.abs(got / np.exp(xs.astype(np.float32).astype(np.float64)) - 1.0)) < 3e-7
+
+
+def test_nan_policy_is_propagation(oracle):
+    """the reference propagates NaN (argmin of a NaN row is unspecified); the oracle and
+    the kernels do the same — a NaN voxel poisons only its own leaf."""
+    leaves = synth.make_leaves(3, seed=4)
+    clean = oracle.encode(leaves)
+    leaves[1, 100] = np.nan
+    got = oracle.encode(leaves)
+    assert np.array_equal(got[0], clean[0]) and np.array_equal(got[2], clean[2])
