@@ -74,12 +74,17 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------
-// E1: Conv3d(1->16,k3,p1) @8^3 (VQVAE_v2.py:235) + GroupNorm(4,16) statistics (:236).
-// 16x16x4 MFMA: rows = 16 couts, cols = 16 leaves, K = (kd,kh) x {kw0,kw1,kw2,pad}.
-// A wave owns a 32-leaf tile (two 16-leaf sub-tiles) and a full output row of 8 positions
-// (16 independent accumulators); steps = (output row, valid (kd,kh)), next step's 16 input
-// dwords are prefetched while the current 16 MFMAs issue.
+// E1-E2: Conv3d(1->16,k3,p1) @8^3 (VQVAE_v2.py:235) + GroupNorm(4,16) + ReLU (:236-237) and the
+// statistics of the result for ResidualBlock.gn1 (:205).
+// 16x16x4 MFMA: rows = 16 couts, cols = 16 leaves, K = (kd,kh) x {kw0,kw1,kw2,pad}.  A wave owns a
+// 32-leaf tile (two 16-leaf sub-tiles) and a full output row of 8 positions (16 independent
+// accumulators); one step = (output row, valid kd) = up to 3 kh x 16 MFMAs, the next step's 48 input
+// dwords are prefetched meanwhile.  The conv is so cheap (221 k MAC/leaf) that it is run TWICE instead
+// of materialising its 32 KiB/leaf output:
+//   MODE 0: statistics of y1 = conv(x)+bias for GroupNorm(4,16) (no activation store unless A.out != 0)
+//   MODE 1: recompute y1, a1 = relu(gn(y1)) -> store, statistics of a1 for GroupNorm(8,16).
 // ------------------------------------------------------------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __restrict__ steps)
 {
     const int lane = threadIdx.x & 63;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
     for (int t = 0; t < 9; ++t) w[t] = A.wfrag[t * 64 + lane];
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
     const float* x = A.in + (size_t)tile * 512 * 32 + jj;
-    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+    f32x4* out4 = A.out ? (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
     // per-lane input column offsets of the 8 outputs of a row: iw = ow + q4 - 1 (pad slot / halo -> 0)
     int off[8];
     bool ok[8];
@@ -102,17 +107,38 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
         ok[ow] = (q4 < 3) && iw >= 0 && iw < 8;
         off[ow] = (ok[ow] ? iw : 0) * 32;
     }
-    GnAcc st[2];
-    st[0].init();
-    st[1].init();
+    float ia[2][4], ib[2][4];  // MODE 1: GroupNorm(4,16) of y1, group = q4 (this lane's 4 couts)
+    if (MODE == 1) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            const float mean = A.in_mean[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj];
+            const float rstd = A.in_rstd[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ia[sb][i] = rstd * A.in_gamma[4 * q4 + i];
+                ib[sb][i] = __builtin_fmaf(-mean, ia[sb][i], A.in_beta[4 * q4 + i]);
+            }
+        }
+    }
+    GnAcc st[2][MODE == 1 ? 2 : 1];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int k = 0; k < (MODE == 1 ? 2 : 1); ++k) st[sb][k].init();
+
     const int NS = A.n_steps;
     int4 e = steps[0];
     int4 en = steps[1];
-    float xn[8][2];
+    // step entry: x = centre input row base (id*8+oh)*8, y = kd, w bits 8..10 = valid kh mask
+    float xn[3][8][2];
 #pragma unroll
-    for (int ow = 0; ow < 8; ++ow) {
-        xn[ow][0] = x[e.x * 32 + off[ow]];
-        xn[ow][1] = x[e.x * 32 + off[ow] + 16];
+    for (int kh = 0; kh < 3; ++kh) {
+        const int rb = max(0, min(e.x + (kh - 1) * 8, 504)) * 32;
+#pragma unroll
+        for (int ow = 0; ow < 8; ++ow) {
+            xn[kh][ow][0] = x[rb + off[ow]];
+            xn[kh][ow][1] = x[rb + off[ow] + 16];
+        }
     }
     int si = 0;
     for (int row = 0; row < 64; ++row) {
@@ -121,26 +147,38 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
         for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
         bool last;
         do {
-            float xc[8][2];
+            float xc[3][8][2];
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) {
-                xc[ow][0] = ok[ow] ? xn[ow][0] : 0.0f;
-                xc[ow][1] = ok[ow] ? xn[ow][1] : 0.0f;
-            }
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int ow = 0; ow < 8; ++ow) {
+                    xc[kh][ow][0] = ok[ow] ? xn[kh][ow][0] : 0.0f;
+                    xc[kh][ow][1] = ok[ow] ? xn[kh][ow][1] : 0.0f;
+                }
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) {  // unconditional: en is clamped to the last entry
-                xn[ow][0] = x[en.x * 32 + off[ow]];
-                xn[ow][1] = x[en.x * 32 + off[ow] + 16];
+            for (int kh = 0; kh < 3; ++kh) {  // unconditional, clamped: rows outside the leaf are never used (mask)
+                const int rb = max(0, min(en.x + (kh - 1) * 8, 504)) * 32;
+#pragma unroll
+                for (int ow = 0; ow < 8; ++ow) {
+                    xn[kh][ow][0] = x[rb + off[ow]];
+                    xn[kh][ow][1] = x[rb + off[ow] + 16];
+                }
             }
-            // e.y = kd*3+kh selects the weight register; a 9-way uniform switch keeps the index static
-            float wv = w[0];
+            // e.y = kd selects the weight registers; a 3-way uniform select keeps the register index static
+            const float w0 = e.y == 0 ? w[0] : (e.y == 1 ? w[3] : w[6]);
+            const float w1 = e.y == 0 ? w[1] : (e.y == 1 ? w[4] : w[7]);
+            const float w2 = e.y == 0 ? w[2] : (e.y == 1 ? w[5] : w[8]);
 #pragma unroll
-            for (int t = 1; t < 9; ++t) wv = (e.y == t) ? w[t] : wv;
+            for (int kh = 0; kh < 3; ++kh) {
+                if ((e.w >> (8 + kh)) & 1) {
+                    const float wv = kh == 0 ? w0 : (kh == 1 ? w1 : w2);
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) {
-                acc[ow][0] = mfma16(wv, xc[ow][0], acc[ow][0]);
-                acc[ow][1] = mfma16(wv, xc[ow][1], acc[ow][1]);
+                    for (int ow = 0; ow < 8; ++ow) {
+                        acc[ow][0] = mfma16(wv, xc[kh][ow][0], acc[ow][0]);
+                        acc[ow][1] = mfma16(wv, xc[kh][ow][1], acc[ow][1]);
+                    }
+                }
             }
             last = (e.w & 2) != 0;
             e = en;
@@ -151,20 +189,42 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
         for (int ow = 0; ow < 8; ++ow)
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
-                const f32x4 v = acc[ow][sb] + bias4;
-                out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;
-                st[sb].add(v.x);
-                st[sb].add(v.y);
-                st[sb].add(v.z);
-                st[sb].add(v.w);
+                f32x4 v = acc[ow][sb] + bias4;
+                if (MODE == 0) {
+                    if (out4) out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;   // debug only
+                    st[sb][0].add(v.x);
+                    st[sb][0].add(v.y);
+                    st[sb][0].add(v.z);
+                    st[sb][0].add(v.w);
+                } else {
+                    v.x = fmaxf(__builtin_fmaf(v.x, ia[sb][0], ib[sb][0]), 0.0f);
+                    v.y = fmaxf(__builtin_fmaf(v.y, ia[sb][1], ib[sb][1]), 0.0f);
+                    v.z = fmaxf(__builtin_fmaf(v.z, ia[sb][2], ib[sb][2]), 0.0f);
+                    v.w = fmaxf(__builtin_fmaf(v.w, ia[sb][3], ib[sb][3]), 0.0f);
+                    out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;
+                    st[sb][0].add(v.x);
+                    st[sb][0].add(v.y);
+                    st[sb][1].add(v.z);
+                    st[sb][1].add(v.w);
+                }
             }
     }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
-        float m, r;
-        gn_finish(st[sb].s, st[sb].q, 1.0 / 2048.0, m, r);
-        A.out_mean[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj] = m;
-        A.out_rstd[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj] = r;
+        if (MODE == 0) {
+            float m, r;
+            gn_finish(st[sb][0].s, st[sb][0].q, 1.0 / 2048.0, m, r);
+            A.out_mean[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj] = m;
+            A.out_rstd[((size_t)tile * 4 + q4) * 32 + 16 * sb + jj] = r;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float m, r;
+                gn_finish(st[sb][k].s, st[sb][k].q, 1.0 / 1024.0, m, r);
+                A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * sb + jj] = m;
+                A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * sb + jj] = r;
+            }
+        }
     }
 }
 
