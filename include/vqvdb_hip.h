@@ -16,8 +16,9 @@
  * Every function returns VQHIP_OK (0) or a negative status; the message is available from
  * vqhip_last_error().  Nothing throws, nothing aborts.  A codec handle owns its device
  * buffers and streams; distinct handles may be used from distinct threads concurrently,
- * one handle is used by one thread at a time (the reference orchestrator calls
- * encode/decode serially: VQVAECodec.cpp:108-127,166-196).
+ * one handle is used by one thread at a time and has ONE call in flight (its activation
+ * workspace is shared by consecutive calls; the reference orchestrator calls encode/decode
+ * serially: VQVAECodec.cpp:108-127,166-196).
  */
 #ifndef VQVDB_HIP_H
 #define VQVDB_HIP_H
