@@ -69,11 +69,22 @@ def profile_pass(codec, fn, steps, device, flop_key):
     return out
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/hbm_traffic_per_launch.json,
+    tools/make_traffic_json.py): FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE.  None if not profiled."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))[kernel]
+        return {"bytes": t["fetch_bytes"] + t["write_bytes"], "fetch_bytes": t["fetch_bytes"], "write_bytes": t["write_bytes"],
+                "source": t["source"], "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at 65536 leaves per launch; " + t["correction"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline_of(kernels, total_flop_per_leaf, leaves_per_s_per_gpu):
     dom = max(kernels, key=lambda k: k["avg_ms"])
     return {
         "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_TF, "unit": "TFLOP/s",
-        "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": None,
+        "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": hbm_traffic(dom["kernel"]),
         "achieved_effective": dom["tflops_effective"], "avg_launch_ms": dom["avg_ms"],
         "whole_path_frac": round(leaves_per_s_per_gpu * total_flop_per_leaf / (PEAK_TF * 1e12), 4),
         "note": "achieved = nominal dense FLOP per leaf of the reference ops this kernel replaces (SURVEY App. A, padding taps counted) "

@@ -75,6 +75,13 @@ int vqhip_decode(vqhip_codec* codec, const uint8_t* indices, int64_t n_leaves, f
 int vqhip_encode_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, uint8_t* indices_dev, void* hip_stream);
 int vqhip_decode_device(vqhip_codec* codec, const uint8_t* indices_dev, int64_t n_leaves, float* leaves_dev, void* hip_stream);
 
+/* Leaf-pointer variants (extension; no reference counterpart).  leaf_ptrs[i] points at the
+ * 512 floats of leaf i (e.g. an OpenVDB LeafNode buffer, leaf.buffer().data()).  The library gathers /
+ * scatters with its own host threads through pinned staging, which replaces the orchestrator's packing loop
+ * and per-batch std::vector (VQVAECodec.cpp:36-59) and its unpack memcpy (VQVAECodec.cpp:182-192). */
+int vqhip_encode_leaves(vqhip_codec* codec, const float* const* leaf_ptrs, int64_t n_leaves, uint8_t* indices);
+int vqhip_decode_leaves(vqhip_codec* codec, const uint8_t* indices, int64_t n_leaves, float* const* leaf_ptrs);
+
 /* Leaves processed per internal pass (default 65536).  Bounds the device workspace
  * (about 0.26 MB per leaf). */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);

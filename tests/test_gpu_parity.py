@@ -208,3 +208,20 @@ def test_config2_one_million_leaves_permutation_property(codec, oracle):
     rec = codec.decode(idx[:200_000])
     base_rec = codec.decode(base_idx)
     assert np.array_equal(_bits(rec), _bits(base_rec[perm[:200_000]]))
+
+
+def test_leaf_pointer_entry_points(pack):
+    """scattered per-leaf buffers in, scattered per-leaf buffers out, across chunk boundaries."""
+    c = HipCodec(pack)
+    c.set_chunk_leaves(4096)
+    leaves = synth.make_leaves(10000, seed=31)
+    order = np.random.default_rng(1).permutation(10000)
+    pool = leaves[order].copy()                       # leaf i lives at pool[inv[i]] — non-contiguous w.r.t. leaf order
+    inv = np.argsort(order)
+    want = c.encode(leaves)
+    got = c.encode_leaves([pool[inv[i]] for i in range(10000)])
+    assert np.array_equal(got, want)
+    out_pool = np.zeros_like(pool)
+    c.decode_leaves(want, [out_pool[inv[i]] for i in range(10000)])
+    assert np.array_equal(_bits(out_pool[inv]), _bits(c.decode(want)))
+    c.close()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic_per_launch.json from the FETCH_SIZE / WRITE_SIZE PMC passes (rocpd sqlite).
+bench.py reports roofline.traffic from this file (it cannot collect PMC counters itself).
+FETCH_SIZE is doubled per the gfx950 calibration of MI355X_MICROARCH.md §HBM (verified here: the
+elementwise kernel's corrected 2050 MB vs 2048 MB algorithmic); WRITE_SIZE is used as reported."""
+import json
+import re
+import sqlite3
+import sys
+
+LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the library's profiler)
+    (r"conv_first_k<0>", "enc_conv_first_stats"), (r"conv_first_k<1>", "enc_conv_first_gn"),
+    (r"conv8_c16_k<false, true>", "enc_res16_conv1"), (r"conv8_c16_k<true, false>", "enc_res16_conv2"),
+    (r"conv_mfma32_k<16, 32, 512", "enc_down"),
+    (r"conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false", "enc_res32_conv1"),
+    (r"conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true", "enc_res32_conv2"),
+    (r"proj_vq_k", "enc_proj_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
+    (r"gn_relu_stats_k<64", "dec_gn_relu_stats"),
+    (r"conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false", "dec_res64_conv1"),
+    (r"conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true", "dec_res64_conv2"),
+    (r"conv_mfma32_k<64, 128, 64, 4,", "dec_tail"),
+]
+
+
+def read(path, counter):
+    db = sqlite3.connect(path)
+    out = {}
+    for name, avg in db.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
+        for rx, launch in LAUNCH:
+            if re.search(rx, name) and not name.startswith("build_"):
+                out[launch] = avg * 1024.0
+    return out
+
+
+def main():
+    fetch_db, write_db, source, out = sys.argv[1:5]
+    f, w = read(fetch_db, "FETCH_SIZE"), read(write_db, "WRITE_SIZE")
+    res = {k: {"fetch_bytes": round(2.0 * f[k]), "write_bytes": round(w.get(k, 0.0)), "leaves_per_launch": 65536, "source": source,
+               "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE as reported"} for k in f}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print(out, len(res), "kernels")
+
+
+if __name__ == "__main__":
+    main()

@@ -85,7 +85,7 @@ class _KernelStat(ctypes.Structure):
 # every symbol include/vqvdb_hip.h declares
 ABI_SYMBOLS = [
     "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_latent_shape", "vqhip_encode", "vqhip_decode",
-    "vqhip_encode_device", "vqhip_decode_device", "vqhip_set_chunk_leaves", "vqhip_profile_enable",
+    "vqhip_encode_device", "vqhip_decode_device", "vqhip_encode_leaves", "vqhip_decode_leaves", "vqhip_set_chunk_leaves", "vqhip_profile_enable",
     "vqhip_profile_read", "vqhip_debug_enable", "vqhip_debug_fetch", "vqhip_selftest_mfma", "vqhip_version",
 ]
 
@@ -111,6 +111,8 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_decode.argtypes = [vp, vp, i64, vp]
     lib.vqhip_encode_device.argtypes = [vp, vp, i64, vp, vp]
     lib.vqhip_decode_device.argtypes = [vp, vp, i64, vp, vp]
+    lib.vqhip_encode_leaves.argtypes = [vp, vp, i64, vp]
+    lib.vqhip_decode_leaves.argtypes = [vp, vp, i64, vp]
     lib.vqhip_set_chunk_leaves.argtypes = [vp, i64]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
     lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
@@ -166,6 +168,20 @@ class HipCodec:
         out = np.empty((indices.shape[0], LEAF_VOXELS), dtype=np.float32)
         self._check(self._lib.vqhip_decode(self._h, indices.ctypes.data, indices.shape[0], out.ctypes.data))
         return out
+
+    def encode_leaves(self, leaf_arrays: Sequence[np.ndarray]) -> np.ndarray:
+        """Leaf-pointer entry point: one 512-float buffer per leaf (e.g. OpenVDB leaf buffers)."""
+        n = len(leaf_arrays)
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in leaf_arrays])
+        idx = np.empty((n, LATENT_VOXELS), dtype=np.uint8)
+        self._check(self._lib.vqhip_encode_leaves(self._h, ptrs, n, idx.ctypes.data))
+        return idx
+
+    def decode_leaves(self, indices: np.ndarray, leaf_arrays: Sequence[np.ndarray]) -> None:
+        indices = np.ascontiguousarray(indices, dtype=np.uint8).reshape(-1, LATENT_VOXELS)
+        n = indices.shape[0]
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in leaf_arrays])
+        self._check(self._lib.vqhip_decode_leaves(self._h, indices.ctypes.data, n, ptrs))
 
     def encode_device(self, leaves_ptr: int, n: int, idx_ptr: int, stream: int = 0):
         self._check(self._lib.vqhip_encode_device(self._h, leaves_ptr, n, idx_ptr, stream or None))

@@ -12,6 +12,7 @@
 #include <fstream>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vqvdb_hip.h"
@@ -86,6 +87,8 @@ struct vqhip_codec {
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     void* pin_out[2] = {nullptr, nullptr};   // pinned landing zone for results (chunk * 2048 B each)
+    void* pin_in[2] = {nullptr, nullptr};    // pinned gather buffers of the leaf-pointer entry points (lazy)
+    int64_t pin_in_leaves = 0;
     float* dev_leaves[2] = {nullptr, nullptr};  // chunk * 512 floats
     uint8_t* dev_idx[2] = {nullptr, nullptr};   // chunk * 64 bytes
     int64_t dev_io_leaves = 0;
@@ -700,23 +703,58 @@ int ensure_io(vqhip_codec* c, int64_t n)
     return VQHIP_OK;
 }
 
+// parallel-for over [0,n) on host threads (the library's stand-in for the orchestrator's tbb::parallel_for)
+template <typename F>
+void host_parallel_for(int64_t n, F&& f)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw / 2, (int64_t)16, n / 2048}));
+    if (nt <= 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) th.emplace_back([=, &f] { f(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    for (auto& x : th) x.join();
+}
+
 // Host-pointer pipeline (the path the reference orchestrator calls, VQVAECodec.cpp:120,178).
 // Chunk i: H2D on s_in -> kernels on the compute stream -> D2H into pinned memory on s_out; the host
 // thread copies chunk i-1's result to the caller while the GPU works on chunk i.  encode: in = leaves
 // (2048 B/leaf), out = indices (64 B/leaf); decode: the reverse.
-int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out, int64_t n)
+// in_ptrs / out_ptrs (leaf-pointer entry points): per-leaf buffers instead of one contiguous block.
+int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out, int64_t n, const float* const* in_ptrs = nullptr,
+                      float* const* out_ptrs = nullptr)
 {
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t step = std::min(c->chunk, n);
     int rc = ensure_io(c, step);
     if (rc) return rc;
+    if (in_ptrs && c->pin_in_leaves < step) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
+            c->pin_in[i] = nullptr;
+        }
+        c->pin_in_leaves = 0;
+        for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc(&c->pin_in[i], (size_t)step * 2048, hipHostMallocDefault));
+        c->pin_in_leaves = step;
+    }
     const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
     int64_t prev_off = -1, prev_m = 0;
     int prev_slot = 0, i = 0;
     auto drain = [&]() -> int {
         if (prev_off < 0) return VQHIP_OK;
         HIPCHK(c, hipEventSynchronize(c->ev_out[prev_slot]));
-        std::memcpy(static_cast<char*>(out) + (size_t)prev_off * out_b, c->pin_out[prev_slot], (size_t)prev_m * out_b);
+        if (out_ptrs) {
+            const float* src = static_cast<const float*>(c->pin_out[prev_slot]);
+            float* const* dst = out_ptrs + prev_off;
+            host_parallel_for(prev_m, [=](int64_t a, int64_t b) {
+                for (int64_t l = a; l < b; ++l) std::memcpy(dst[l], src + l * 512, 2048);
+            });
+        } else {
+            std::memcpy(static_cast<char*>(out) + (size_t)prev_off * out_b, c->pin_out[prev_slot], (size_t)prev_m * out_b);
+        }
         prev_off = -1;
         return VQHIP_OK;
     };
@@ -726,7 +764,17 @@ int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out,
         void* d_in = is_encode ? (void*)c->dev_leaves[slot] : (void*)c->dev_idx[slot];
         void* d_out = is_encode ? (void*)c->dev_idx[slot] : (void*)c->dev_leaves[slot];
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0));   // slot's previous input consumed
-        HIPCHK(c, hipMemcpyAsync(d_in, static_cast<const char*>(in) + (size_t)o * in_b, (size_t)m * in_b, hipMemcpyHostToDevice, c->s_in));
+        const void* src = static_cast<const char*>(in) + (size_t)o * in_b;
+        if (in_ptrs) {
+            if (i >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[slot]));  // the H2D that last read this pinned buffer is done
+            float* stage = static_cast<float*>(c->pin_in[slot]);
+            const float* const* lp = in_ptrs + o;
+            host_parallel_for(m, [=](int64_t a, int64_t b) {
+                for (int64_t l = a; l < b; ++l) std::memcpy(stage + l * 512, lp[l], 2048);
+            });
+            src = stage;
+        }
+        HIPCHK(c, hipMemcpyAsync(d_in, src, (size_t)m * in_b, hipMemcpyHostToDevice, c->s_in));
         HIPCHK(c, hipEventRecord(c->ev_in[slot], c->s_in));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[slot], 0));  // slot's previous output drained to pinned
@@ -816,6 +864,7 @@ void vqhip_destroy(vqhip_codec* c)
         if (c->dev_leaves[i]) hipFree(c->dev_leaves[i]);
         if (c->dev_idx[i]) hipFree(c->dev_idx[i]);
         if (c->pin_out[i]) hipHostFree(c->pin_out[i]);
+        if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
         if (c->ev_in[i]) hipEventDestroy(c->ev_in[i]);
         if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
         if (c->ev_out[i]) hipEventDestroy(c->ev_out[i]);
@@ -885,6 +934,20 @@ int vqhip_decode(vqhip_codec* c, const uint8_t* indices, int64_t n, float* leave
     if (!c) return VQHIP_ERR_INVALID;
     if (!leaves || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode: null pointer or n_leaves < 1");
     return run_host_pipeline(c, false, indices, leaves, n);
+}
+
+int vqhip_encode_leaves(vqhip_codec* c, const float* const* leaf_ptrs, int64_t n, uint8_t* indices)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!leaf_ptrs || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "encode_leaves: null pointer or n_leaves < 1");
+    return run_host_pipeline(c, true, nullptr, indices, n, leaf_ptrs, nullptr);
+}
+
+int vqhip_decode_leaves(vqhip_codec* c, const uint8_t* indices, int64_t n, float* const* leaf_ptrs)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!leaf_ptrs || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode_leaves: null pointer or n_leaves < 1");
+    return run_host_pipeline(c, false, indices, nullptr, n, nullptr, leaf_ptrs);
 }
 
 int vqhip_debug_enable(vqhip_codec* c, int enable)
