@@ -102,10 +102,10 @@ typedef struct vqhip_kernel_stat {
 int vqhip_profile_enable(vqhip_codec* codec, int enable);
 int vqhip_profile_read(vqhip_codec* codec, vqhip_kernel_stat* stats, int cap, int* count);
 
-/* Test hooks.  vqhip_debug_enable(1) makes encode also keep the 128-channel latent (it is
- * otherwise never written to memory).  vqhip_debug_fetch copies an intermediate activation
+/* Test hooks.  vqhip_debug_enable(1) makes encode also store the first conv's raw output (it is
+ * otherwise recomputed, never written).  vqhip_debug_fetch copies an intermediate activation
  * of the LAST encode/decode chunk to host as float32 [n_leaves][C][positions] (NCDHW
- * flattened).  Names: e_y1 e_a1 e_y4 e_a6 e_x7 e_y9 e_x11 e_z d_ystem d_d2 d_y4 d_x6. */
+ * flattened).  Names: e_y1 e_a1 e_y4 e_a6 e_x7 e_y9 e_x11 d_ystem d_d2 d_y4 d_x6. */
 int vqhip_debug_enable(vqhip_codec* codec, int enable);
 int vqhip_debug_fetch(vqhip_codec* codec, const char* name, int64_t n_leaves, float* out);
 

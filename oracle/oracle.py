@@ -45,6 +45,9 @@ class Oracle:
             f.restype = ctypes.c_int
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                           ctypes.c_void_p, ctypes.c_int]
+        self.lib.vqo_encode_ex.restype = ctypes.c_int
+        self.lib.vqo_encode_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         self.lib.vqo_decode_ex.restype = ctypes.c_int
         self.lib.vqo_decode_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
@@ -62,12 +65,14 @@ class Oracle:
                 ptrs[i] = bufs[name].ctypes.data
         return ptrs, bufs
 
-    def encode(self, leaves: np.ndarray, threads: int = 1, debug=()):
+    def encode(self, leaves: np.ndarray, threads: int = 1, debug=(), faithful: bool = False):
+        """faithful=True quantizes with the reference's expanded fp32 distance on the materialised latent
+        (VQVAE_v2.py:364-366) instead of the folded search the GPU runs; same argmin up to near-ties."""
         leaves = np.ascontiguousarray(leaves, dtype=np.float32).reshape(-1, 512)
         B = leaves.shape[0]
         idx = np.zeros((B, 64), dtype=np.uint8)
         ptrs, bufs = self._dbg(B, set(debug))
-        rc = self.lib.vqo_encode(self._wptr, leaves.ctypes.data, B, idx.ctypes.data, ptrs, threads)
+        rc = self.lib.vqo_encode_ex(self._wptr, leaves.ctypes.data, B, idx.ctypes.data, ptrs, threads, int(faithful))
         if rc:
             raise RuntimeError("oracle encode failed")
         return (idx, bufs) if debug else idx

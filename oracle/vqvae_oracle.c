@@ -38,10 +38,16 @@
  *   * residual: out = skip + (0.1f * (acc + bias))      (two roundings)
  *   * channel attention: mean = (sum over positions ascending) * (1/64); fc chains ascending;
  *     sigmoid(x) = 1/(1+vq_expf(-x)) with the polynomial vq_expf below.
- *   * VQ: dist = (zz + ee[k]) - 2*dot[k]  (VQVAE_v2.py:364-366), dot in "P8" order over the
- *     128 latent channels, zz = partial(channels c with (c&4)==0) + partial((c&4)!=0), each
- *     partial an fmaf chain over ascending c; ee[k] an fmaf chain over ascending c;
- *     argmin = first minimum (torch.argmin).
+ *   * VQ (default, what the GPU runs): the 1x1x1 projection z = P x' + b (VQVAE_v2.py:243) is folded into
+ *     the nearest-code search (:364-367).  ||z||^2 is the same for every code, and
+ *     z.e_k = x'.(P^T e_k) + b.e_k, so  argmin_k dist_k = argmin_k [ c_k - 2 * (x' . Ep_k) ]  with
+ *       Ep_k[c] = (float) sum_j fma(e_k[j], P[j][c], .)            (fp64 chain, j ascending)
+ *       c_k     = (float) ( sum_j e_k[j]^2 - 2 * sum_j b[j] e_k[j] )  (fp64 chains, j ascending)
+ *       x'.Ep_k = fmaf chain over the 32 gated channels in "P8" order from 0
+ *     score = c_k - 2*dot; argmin = first minimum (torch.argmin).  Exact algebra; it differs from
+ *     the reference's fp32 expression only in rounding, i.e. only on near-ties.
+ *   * VQ (faithful cross-check, vqo_encode_ex(faithful=1)): z = conv1x1, dist = (zz + ee[k]) - 2*dot[k]
+ *     exactly as VQVAE_v2.py:364-366, dot in "P8" order over the 128 latent channels.
  */
 #include <math.h>
 #include <stdint.h>
@@ -483,8 +489,31 @@ typedef struct {
     float *a, *b, *c, *d; /* scratch, each 256*64*LT = 16*512*LT*2 floats */
 } scratch_t;
 
+/* projection folded into the codebook (see the VQ contract in the header) */
+typedef struct {
+    float ep[256 * 32];
+    float ck[256];
+} vqfold_t;
+
+static void vqfold_build(vqfold_t* f, const float* E /*[256][128]*/, const float* P /*[128][32]*/, const float* b /*[128]*/)
+{
+    for (int k = 0; k < 256; ++k) {
+        for (int c = 0; c < 32; ++c) {
+            double a = 0.0;
+            for (int j = 0; j < 128; ++j) a = fma((double)E[k * 128 + j], (double)P[j * 32 + c], a);
+            f->ep[k * 32 + c] = (float)a;
+        }
+        double cc = 0.0, bb = 0.0;
+        for (int j = 0; j < 128; ++j) {
+            cc = fma((double)E[k * 128 + j], (double)E[k * 128 + j], cc);
+            bb = fma((double)b[j], (double)E[k * 128 + j], bb);
+        }
+        f->ck[k] = (float)(cc - 2.0 * bb);
+    }
+}
+
 static void encode_tile(const float* const* W, const float* leaves, int64_t leaf0, int nl, uint8_t* idx,
-                        float* const* dbg, scratch_t* s, const float* ee)
+                        float* const* dbg, scratch_t* s, const float* ee, const vqfold_t* fold, int faithful)
 {
     int p8_16[16], p16[16], p8_32[32], p8_128[128];
     korder_p8(16, p8_16); korder_p16(p16); korder_p8(32, p8_32); korder_p8(128, p8_128);
@@ -518,36 +547,65 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
     float* x12 = s->a;
     channel_attention(x11, x12, 32, W[W_E_FC0], W[W_E_FC2]);
     if (dbg) dump(dbg[DBG_E_X12], x12, 32, 64, leaf0, nl);
-    float* z = s->b; /* [128][64][LT] */
-    conv3d(x12, z, W[W_E_PROJ_W], W[W_E_PROJ_B], 32, 128, 4, 4, 1, 1, 0, p8_32);
-    if (dbg) dump(dbg[DBG_E_Z], z, 128, 64, leaf0, nl);
-    /* nearest code (VQVAE_v2.py:358-367) */
-    const float* E = W[W_CODEBOOK];
-    for (int p = 0; p < 64; ++p) {
-        float zz0[LT], zz1[LT], zz[LT], best[LT];
-        int bi[LT];
-        for (int l = 0; l < LT; ++l) { zz0[l] = zz1[l] = 0.0f; }
-        for (int c = 0; c < 128; ++c) {
-            const float* v = z + ((size_t)c * 64 + p) * LT;
-            if ((c & 4) == 0) for (int l = 0; l < LT; ++l) zz0[l] = fmaf(v[l], v[l], zz0[l]);
-            else for (int l = 0; l < LT; ++l) zz1[l] = fmaf(v[l], v[l], zz1[l]);
+    if (faithful || (dbg && dbg[DBG_E_Z])) {
+        float* z = s->b; /* [128][64][LT] */
+        conv3d(x12, z, W[W_E_PROJ_W], W[W_E_PROJ_B], 32, 128, 4, 4, 1, 1, 0, p8_32);
+        if (dbg) dump(dbg[DBG_E_Z], z, 128, 64, leaf0, nl);
+        if (faithful) {
+            /* nearest code, reference expression (VQVAE_v2.py:358-367) */
+            const float* E = W[W_CODEBOOK];
+            for (int p = 0; p < 64; ++p) {
+                float zz0[LT], zz1[LT], zz[LT], best[LT];
+                int bi[LT];
+                for (int l = 0; l < LT; ++l) { zz0[l] = zz1[l] = 0.0f; }
+                for (int c = 0; c < 128; ++c) {
+                    const float* v = z + ((size_t)c * 64 + p) * LT;
+                    if ((c & 4) == 0) for (int l = 0; l < LT; ++l) zz0[l] = fmaf(v[l], v[l], zz0[l]);
+                    else for (int l = 0; l < LT; ++l) zz1[l] = fmaf(v[l], v[l], zz1[l]);
+                }
+                for (int l = 0; l < LT; ++l) { zz[l] = zz0[l] + zz1[l]; best[l] = INFINITY; bi[l] = 0; }
+                for (int k0 = 0; k0 < 256; k0 += 4) {
+                    float dot[4][LT];
+                    for (int b = 0; b < 4; ++b) for (int l = 0; l < LT; ++l) dot[b][l] = 0.0f;
+                    for (int cc = 0; cc < 128; ++cc) {
+                        const int c = p8_128[cc];
+                        const float* v = z + ((size_t)c * 64 + p) * LT;
+                        for (int b = 0; b < 4; ++b) {
+                            const float e = E[(k0 + b) * 128 + c];
+                            for (int l = 0; l < LT; ++l) dot[b][l] = fmaf(e, v[l], dot[b][l]);
+                        }
+                    }
+                    for (int b = 0; b < 4; ++b)
+                        for (int l = 0; l < LT; ++l) {
+                            const float d = (zz[l] + ee[k0 + b]) - 2.0f * dot[b][l];
+                            if (d < best[l]) { best[l] = d; bi[l] = k0 + b; }
+                        }
+                }
+                for (int l = 0; l < nl; ++l) idx[(size_t)(leaf0 + l) * 64 + p] = (uint8_t)bi[l];
+            }
+            return;
         }
-        for (int l = 0; l < LT; ++l) { zz[l] = zz0[l] + zz1[l]; best[l] = INFINITY; bi[l] = 0; }
+    }
+    /* nearest code with the projection folded in (default) */
+    for (int p = 0; p < 64; ++p) {
+        float best[LT];
+        int bi[LT];
+        for (int l = 0; l < LT; ++l) { best[l] = INFINITY; bi[l] = 0; }
         for (int k0 = 0; k0 < 256; k0 += 4) {
             float dot[4][LT];
             for (int b = 0; b < 4; ++b) for (int l = 0; l < LT; ++l) dot[b][l] = 0.0f;
-            for (int cc = 0; cc < 128; ++cc) {
-                const int c = p8_128[cc];
-                const float* v = z + ((size_t)c * 64 + p) * LT;
+            for (int cc = 0; cc < 32; ++cc) {
+                const int c = p8_32[cc];
+                const float* v = x12 + ((size_t)c * 64 + p) * LT;
                 for (int b = 0; b < 4; ++b) {
-                    const float e = E[(k0 + b) * 128 + c];
+                    const float e = fold->ep[(k0 + b) * 32 + c];
                     for (int l = 0; l < LT; ++l) dot[b][l] = fmaf(e, v[l], dot[b][l]);
                 }
             }
             for (int b = 0; b < 4; ++b)
                 for (int l = 0; l < LT; ++l) {
-                    const float d = (zz[l] + ee[k0 + b]) - 2.0f * dot[b][l];
-                    if (d < best[l]) { best[l] = d; bi[l] = k0 + b; }
+                    const float sc = fold->ck[k0 + b] - 2.0f * dot[b][l];
+                    if (sc < best[l]) { best[l] = sc; bi[l] = k0 + b; }
                 }
         }
         for (int l = 0; l < nl; ++l) idx[(size_t)(leaf0 + l) * 64 + p] = (uint8_t)bi[l];
@@ -627,11 +685,21 @@ void vqo_code_norms(const float* E, float* ee)
     }
 }
 
+/* faithful != 0: quantize with the reference's expanded fp32 distance on the materialised latent */
+int vqo_encode_ex(const float* const* W, const float* leaves, int64_t B, uint8_t* idx, float* const* dbg, int nthreads, int faithful);
+
 int vqo_encode(const float* const* W, const float* leaves, int64_t B, uint8_t* idx, float* const* dbg, int nthreads)
+{
+    return vqo_encode_ex(W, leaves, B, idx, dbg, nthreads, 0);
+}
+
+int vqo_encode_ex(const float* const* W, const float* leaves, int64_t B, uint8_t* idx, float* const* dbg, int nthreads, int faithful)
 {
     if (B <= 0) return 0;
     float ee[256];
     vqo_code_norms(W[W_CODEBOOK], ee);
+    vqfold_t* fold = (vqfold_t*)malloc(sizeof(vqfold_t));
+    vqfold_build(fold, W[W_CODEBOOK], W[W_E_PROJ_W], W[W_E_PROJ_B]);
     const int64_t ntiles = (B + LT - 1) / LT;
     int err = 0;
     if (nthreads < 1) nthreads = 1;
@@ -645,11 +713,12 @@ int vqo_encode(const float* const* W, const float* leaves, int64_t B, uint8_t* i
 #pragma omp for schedule(dynamic, 1)
             for (int64_t t = 0; t < ntiles; ++t) {
                 const int nl = (int)((B - t * LT) < LT ? (B - t * LT) : LT);
-                encode_tile(W, leaves, t * LT, nl, idx, dbg, &s, ee);
+                encode_tile(W, leaves, t * LT, nl, idx, dbg, &s, ee, fold, faithful);
             }
         }
         scratch_free(&s);
     }
+    free(fold);
     return err;
 }
 

@@ -44,7 +44,7 @@ def test_encode_bit_exact_vs_oracle_all_layers(codec, oracle):
     idx = codec.encode(leaves)
     oidx, dbg = oracle.encode(leaves, threads=8, debug=ENC_DEBUG)
     for name in ENC_DEBUG:
-        if name == "e_x12":      # gated activations are never materialised on the GPU
+        if name in ("e_x12", "e_z"):   # gated activations and the 128-channel latent are never formed on the GPU
             continue
         c, p = DEBUG_SHAPES[name]
         assert np.array_equal(_bits(codec.debug_fetch(name, len(leaves), c, p)), _bits(dbg[name])), name

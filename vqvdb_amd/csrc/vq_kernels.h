@@ -700,34 +700,32 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 
 // ------------------------------------------------------------------------------------------
 // Encoder tail: ChannelAttention(32) (VQVAE_v2.py:242) -> Conv3d(32->128,k1) (:243) -> nearest
-// codebook row (:358-367).  Per position the 128-channel latent never leaves registers: the
-// proj MFMA result (D fragment, channel = 32t + (r&3) + 8(r>>2) + 4q) is fed back as the B
-// operand of the distance MFMAs with the codebook pre-shuffled to the same K order.
-// Codebook (128 KB) + proj weights (16 KB) stay in LDS.
+// codebook row (:358-367), with the projection FOLDED into the search:  ||z||^2 is the same for
+// every code and z.e_k = x'.(P^T e_k) + b.e_k, so
+//     argmin_k dist_k = argmin_k [ c_k - 2 * x'.Ep_k ],   Ep = E P  (256 x 32),  c_k = ||e_k||^2 - 2 b.e_k
+// (Ep, c built in fp64 at vqhip_create).  Per position: 8 code tiles x 16 MFMAs on the 32 gated
+// channels instead of 64 (projection) + 512 (128-d distances); the 128-channel latent is never
+// formed.  Ep fragments (32 KB) and c (1 KB) live in LDS.  First-minimum argmin like torch.argmin.
 // ------------------------------------------------------------------------------------------
 struct VqArgs {
     const float* in;        // x11 L4 [tile][64][8][32][4]
     const float* se_csum;   // [tile][32][32]
     const float* se_fc0;    // [8][32]
     const float* se_fc2;    // [32][8]
-    const float* wproj;     // frag [u=4][mt=4][64][4]
-    const float* bproj;     // D-fragment order [(mt*2+q)*16 + r]
-    const float* efrag;     // frag [u=16][ct=8][64][4]
-    const float* ee_frag;   // [(ct*2+q)*16 + r]
+    const float* epfrag;    // A fragments of Ep: [u=4][ct=8][64][4]
+    const float* ck_frag;   // D-fragment order [(ct*2+q)*16 + r]
     uint8_t* idx;           // [n_leaves][64]
-    float* z_dbg;           // optional L4 [tile][64][32][32][4]
     int64_t n_leaves;
     int n_tiles;
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
+__global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    f32x4* ldsE = (f32x4*)smem_raw;          // 16*8*64 float4 = 128 KB
-    f32x4* ldsP = ldsE + 16 * 8 * 64;        // 4*4*64 float4  = 16 KB
-    for (int i = threadIdx.x; i < 16 * 8 * 64; i += NW * 64) ldsE[i] = ((const f32x4*)A.efrag)[i];
-    for (int i = threadIdx.x; i < 4 * 4 * 64; i += NW * 64) ldsP[i] = ((const f32x4*)A.wproj)[i];
+    __shared__ f32x4 ldsE[4 * 8 * 64];  // 32 KB
+    __shared__ f32x4 ldsC[8 * 2 * 4];   // 1 KB
+    for (int i = threadIdx.x; i < 4 * 8 * 64; i += NW * 64) ldsE[i] = ((const f32x4*)A.epfrag)[i];
+    for (int i = threadIdx.x; i < 8 * 2 * 4; i += NW * 64) ldsC[i] = ((const f32x4*)A.ck_frag)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -745,82 +743,60 @@ __global__ __launch_bounds__(NW * 64, 2) void proj_vq_k(VqArgs A)
             for (int i = 0; i < 4; ++i) gate[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
     }
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 8 * 32 + q * 32 + j;
-    const f32x4* bp4 = (const f32x4*)A.bproj;
-    const f32x4* ee4 = (const f32x4*)A.ee_frag;
     const int64_t leaf = (int64_t)tile * 32 + j;
+    f32x4 bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bn[u] = in4[u * 64];
     for (int p = 0; p < 64; ++p) {
-        f32x16 z[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[t][r] = 0.0f;
+        f32x4 b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            f32x4 b = in4[((size_t)p * 8 + 2 * u) * 32];
-            b.x = b.x * gate[u][0];
-            b.y = b.y * gate[u][1];
-            b.z = b.z * gate[u][2];
-            b.w = b.w * gate[u][3];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 w = ldsP[(u * 4 + t) * 64 + lane];
-                z[t] = mfma32(w.x, b.x, z[t]);
-                z[t] = mfma32(w.y, b.y, z[t]);
-                z[t] = mfma32(w.z, b.z, z[t]);
-                z[t] = mfma32(w.w, b.w, z[t]);
-            }
+            b[u].x = bn[u].x * gate[u][0];
+            b[u].y = bn[u].y * gate[u][1];
+            b[u].z = bn[u].z * gate[u][2];
+            b[u].w = bn[u].w * gate[u][3];
         }
-        float zzp = 0.0f;
+        const int pn = p < 63 ? p + 1 : 63;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bias = bp4[(t * 2 + q) * 4 + g];
-                z[t][4 * g + 0] = z[t][4 * g + 0] + bias.x;
-                z[t][4 * g + 1] = z[t][4 * g + 1] + bias.y;
-                z[t][4 * g + 2] = z[t][4 * g + 2] + bias.z;
-                z[t][4 * g + 3] = z[t][4 * g + 3] + bias.w;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) zzp = __builtin_fmaf(z[t][4 * g + i], z[t][4 * g + i], zzp);
-                if (A.z_dbg) {
-                    f32x4 v;
-                    v.x = z[t][4 * g + 0], v.y = z[t][4 * g + 1], v.z = z[t][4 * g + 2], v.w = z[t][4 * g + 3];
-                    ((f32x4*)A.z_dbg)[(((size_t)tile * 64 + p) * 32 + 8 * t + 2 * g + q) * 32 + j] = v;
-                }
-            }
-        const float zzo = __shfl_xor(zzp, 32, 64);
-        const float zz = q == 0 ? zzp + zzo : zzo + zzp;  // partial(c&4==0) + partial(c&4!=0)
+        for (int u = 0; u < 4; ++u) bn[u] = in4[((size_t)pn * 8 + 2 * u) * 32];
         float best = __builtin_inff();
         int bk = 0;
+        const f32x4* el = ldsE + lane;
+#pragma unroll 2
         for (int ct = 0; ct < 8; ++ct) {
-            f32x4 eev[4];  // ||e||^2 of this lane's 16 codes: requested before the 64 MFMAs that hide the latency
+            // the 4 A-fragments and the 16 code constants of this code tile, requested ahead of the MFMAs
+            const f32x4 a0 = el[(0 * 8 + ct) * 64], a1 = el[(1 * 8 + ct) * 64], a2 = el[(2 * 8 + ct) * 64], a3 = el[(3 * 8 + ct) * 64];
+            f32x4 ck[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) eev[g] = ee4[(ct * 2 + q) * 4 + g];
+            for (int g = 0; g < 4; ++g) ck[g] = ldsC[(ct * 2 + q) * 4 + g];
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 e = ldsE[((4 * t + g) * 8 + ct) * 64 + lane];
-                    d = mfma32(e.x, z[t][4 * g + 0], d);
-                    d = mfma32(e.y, z[t][4 * g + 1], d);
-                    d = mfma32(e.z, z[t][4 * g + 2], d);
-                    d = mfma32(e.w, z[t][4 * g + 3], d);
-                    if (g == 3) __builtin_amdgcn_sched_barrier(0);  // keep LDS reads from piling up (VGPR budget)
-                }
+            d = mfma32(a0.x, b[0].x, d);
+            d = mfma32(a0.y, b[0].y, d);
+            d = mfma32(a0.z, b[0].z, d);
+            d = mfma32(a0.w, b[0].w, d);
+            d = mfma32(a1.x, b[1].x, d);
+            d = mfma32(a1.y, b[1].y, d);
+            d = mfma32(a1.z, b[1].z, d);
+            d = mfma32(a1.w, b[1].w, d);
+            d = mfma32(a2.x, b[2].x, d);
+            d = mfma32(a2.y, b[2].y, d);
+            d = mfma32(a2.z, b[2].z, d);
+            d = mfma32(a2.w, b[2].w, d);
+            d = mfma32(a3.x, b[3].x, d);
+            d = mfma32(a3.y, b[3].y, d);
+            d = mfma32(a3.z, b[3].z, d);
+            d = mfma32(a3.w, b[3].w, d);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 ee = eev[g];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float een = i == 0 ? ee.x : (i == 1 ? ee.y : (i == 2 ? ee.z : ee.w));
-                    const float t1 = zz + een;
-                    const float dist = t1 - 2.0f * d[4 * g + i];
+                    const float c = i == 0 ? ck[g].x : (i == 1 ? ck[g].y : (i == 2 ? ck[g].z : ck[g].w));
+                    const float score = c - 2.0f * d[4 * g + i];
                     const int k = 32 * ct + i + 8 * g + 4 * q;
-                    if (dist < best) {
-                        best = dist;
+                    if (score < best) {
+                        best = score;
                         bk = k;
                     }
                 }

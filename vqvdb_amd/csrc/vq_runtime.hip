@@ -52,7 +52,7 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"enc_down", {2.0 * 2097152, 2.0 * 2097152 * 0.669922}},
         {"enc_res32_conv1", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
         {"enc_res32_conv2", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
-        {"enc_proj_vq", {2.0 * (262144 + 2097152 + 512), 2.0 * (262144 + 2097152 + 512)}},
+        {"enc_vq", {2.0 * (262144 + 2097152 + 512), 2.0 * (524288 + 512)}},  // attn + proj + VQ; projection folded into the search
         {"dec_stem", {0.0, 0.0}},  // table lookups: the 14.2 M MAC/leaf of the reference op are not executed (stem_lut_k)
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
@@ -422,21 +422,33 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ed.w", frag32(edw->data, 32, 16, 64)) UP("ed.b", dfrag32(edb->data, 32))
     UP("r32g1.w", r32g1w) UP("r32g1.b", r32g1b) UP("r32c1.w", frag32(r32c1w->data, 32, 32, 27)) UP("r32c1.b", dfrag32(r32c1b->data, 32))
     UP("r32g2.w", r32g2w) UP("r32g2.b", r32g2b) UP("r32c2.w", frag32(r32c2w->data, 32, 32, 27)) UP("r32c2.b", dfrag32(r32c2b->data, 32))
-    UP("efc0", efc0) UP("efc2", efc2) UP("ep.w", frag32(epw->data, 128, 32, 1)) UP("ep.b", dfrag32(epb->data, 128))
+    UP("efc0", efc0) UP("efc2", efc2) 
     UP("ds.w", dsw) UP("ds.b", dsb) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
     UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
     UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
-    UP("cb", cb) UP("cb.frag", frag32(cb->data, 256, 128, 1))
+    UP("cb", cb)
     {
-        // ||e_k||^2: fmaf chain over ascending c (arithmetic contract, oracle vqo_code_norms)
-        std::vector<float> ee(256);
+        // projection folded into the codebook (contract: oracle vqfold_build): Ep = E P in fp64 (j ascending),
+        // c_k = sum e^2 - 2 sum b e, both rounded to fp32 once
+        std::vector<float> ep(256 * 32), ck(256);
+        const float* E = cb->data;
+        const float* P = epw->data;   // [128][32]
         for (int k = 0; k < 256; ++k) {
-            float s = 0.0f;
-            for (int ch = 0; ch < 128; ++ch) s = __builtin_fmaf(cb->data[k * 128 + ch], cb->data[k * 128 + ch], s);
-            ee[k] = s;
+            for (int ch = 0; ch < 32; ++ch) {
+                double acc = 0.0;
+                for (int jx = 0; jx < 128; ++jx) acc = __builtin_fma((double)E[k * 128 + jx], (double)P[jx * 32 + ch], acc);
+                ep[k * 32 + ch] = (float)acc;
+            }
+            double cc = 0.0, bb = 0.0;
+            for (int jx = 0; jx < 128; ++jx) {
+                cc = __builtin_fma((double)E[k * 128 + jx], (double)E[k * 128 + jx], cc);
+                bb = __builtin_fma((double)epb->data[jx], (double)E[k * 128 + jx], bb);
+            }
+            ck[k] = (float)(cc - 2.0 * bb);
         }
-        UP("cb.ee", dfrag32(ee.data(), 256))
+        UP("vq.ep", frag32(ep.data(), 256, 32, 1))
+        UP("vq.ck", dfrag32(ck.data(), 256))
     }
 #undef UP
     if ((rc = upload_i(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
@@ -463,7 +475,7 @@ struct ActSpec {
 };
 const ActSpec kActs[] = {
     {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
-    {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},    {"e_z", 128, 64},
+    {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},
     {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},
     {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64},
 };
@@ -548,7 +560,6 @@ constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, res
 constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
 constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
-constexpr size_t LDS_PROJ_VQ = (size_t)(16 * 8 * 64 + 4 * 4 * 64) * 16;  // 144 KB
 
 int init_kernel_attrs(vqhip_codec* c)
 {
@@ -556,7 +567,6 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_enc_down, LDS_ENC_DOWN))) return rc;
     if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
-    if ((rc = set_lds(c, proj_vq_k<8>, LDS_PROJ_VQ))) return rc;
     return VQHIP_OK;
 }
 
@@ -622,9 +632,8 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     {
         VqArgs A{};
         A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
-        A.wproj = w["ep.w"], A.bproj = w["ep.b"], A.efrag = w["cb.frag"], A.ee_frag = w["cb.ee"];
-        A.idx = d_idx, A.z_dbg = zdbg ? a["e_z"] : nullptr, A.n_leaves = n, A.n_tiles = nt;
-        L.run("enc_proj_vq", [&] { hipLaunchKernelGGL(proj_vq_k<8>, dim3(g8), dim3(512), LDS_PROJ_VQ, s, A); });
+        A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
+        L.run("enc_vq", [&] { hipLaunchKernelGGL(vq_folded_k<8>, dim3(g8), dim3(512), 0, s, A); });
     }
     return L.rc;
 }
