@@ -82,6 +82,17 @@ int vqhip_decode_device(vqhip_codec* codec, const uint8_t* indices_dev, int64_t 
 int vqhip_encode_leaves(vqhip_codec* codec, const float* const* leaf_ptrs, int64_t n_leaves, uint8_t* indices);
 int vqhip_decode_leaves(vqhip_codec* codec, const uint8_t* indices, int64_t n_leaves, float* const* leaf_ptrs);
 
+/* In-process multi-GPU front end (extension): one codec and one host thread per listed
+ * device, device g of G takes the contiguous leaf range [g*ceil(n/G), min(n,(g+1)*ceil(n/G))) of every call
+ * and writes to the same offsets of the caller's buffer.  Weights are replicated; there is no collective.
+ * (Process-per-GPU callers use one plain codec per rank instead: bench.py, vqvdb_amd/sharding.py.) */
+typedef struct vqhip_multi vqhip_multi;
+int vqhip_multi_create(const char* pack_path, const void* pack_bytes, size_t pack_size, const int* device_ids, int n_devices, vqhip_multi** out);
+void vqhip_multi_destroy(vqhip_multi* multi);
+const char* vqhip_multi_last_error(const vqhip_multi* multi);
+int vqhip_multi_encode(vqhip_multi* multi, const float* leaves, int64_t n_leaves, uint8_t* indices);
+int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_leaves, float* leaves);
+
 /* Leaves processed per internal pass (default 65536).  Bounds the device workspace
  * (about 0.26 MB per leaf). */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);

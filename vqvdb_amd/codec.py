@@ -87,6 +87,7 @@ ABI_SYMBOLS = [
     "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_latent_shape", "vqhip_encode", "vqhip_decode",
     "vqhip_encode_device", "vqhip_decode_device", "vqhip_encode_leaves", "vqhip_decode_leaves", "vqhip_set_chunk_leaves", "vqhip_profile_enable",
     "vqhip_profile_read", "vqhip_debug_enable", "vqhip_debug_fetch", "vqhip_selftest_mfma", "vqhip_version",
+    "vqhip_multi_create", "vqhip_multi_destroy", "vqhip_multi_last_error", "vqhip_multi_encode", "vqhip_multi_decode",
 ]
 
 _lib = None
@@ -120,8 +121,15 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_debug_fetch.argtypes = [vp, ctypes.c_char_p, i64, vp]
     lib.vqhip_selftest_mfma.argtypes = [vp, ctypes.POINTER(i64)]
     lib.vqhip_version.restype = ctypes.c_char_p
+    lib.vqhip_multi_create.argtypes = [ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
+    lib.vqhip_multi_destroy.argtypes = [vp]
+    lib.vqhip_multi_destroy.restype = None
+    lib.vqhip_multi_last_error.argtypes = [vp]
+    lib.vqhip_multi_last_error.restype = ctypes.c_char_p
+    lib.vqhip_multi_encode.argtypes = [vp, vp, i64, vp]
+    lib.vqhip_multi_decode.argtypes = [vp, vp, i64, vp]
     for name in ABI_SYMBOLS:
-        if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version"):
+        if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error"):
             getattr(lib, name).restype = ci
     _lib = lib
     return lib
@@ -214,6 +222,45 @@ class HipCodec:
         out = (ctypes.c_int64 * 2)()
         self._check(self._lib.vqhip_selftest_mfma(self._h, out))
         return list(out)
+
+
+class HipMultiCodec:
+    """In-process multi-GPU front end: contiguous leaf ranges over several devices, no collective."""
+
+    def __init__(self, pack: Union[str, os.PathLike, bytes], device_ids: Sequence[int]):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        if isinstance(pack, (bytes, bytearray, memoryview)):
+            self._pack = bytes(pack)
+            rc = self._lib.vqhip_multi_create(None, self._pack, len(self._pack), ids, len(device_ids), ctypes.byref(self._h))
+        else:
+            rc = self._lib.vqhip_multi_create(os.fspath(pack).encode(), None, 0, ids, len(device_ids), ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(self._lib.vqhip_multi_last_error(None).decode())
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(self._lib.vqhip_multi_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.vqhip_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def encode(self, leaves: np.ndarray) -> np.ndarray:
+        leaves = np.ascontiguousarray(leaves, dtype=np.float32).reshape(-1, LEAF_VOXELS)
+        idx = np.empty((leaves.shape[0], LATENT_VOXELS), dtype=np.uint8)
+        self._check(self._lib.vqhip_multi_encode(self._h, leaves.ctypes.data, leaves.shape[0], idx.ctypes.data))
+        return idx
+
+    def decode(self, indices: np.ndarray) -> np.ndarray:
+        indices = np.ascontiguousarray(indices, dtype=np.uint8).reshape(-1, LATENT_VOXELS)
+        out = np.empty((indices.shape[0], LEAF_VOXELS), dtype=np.float32)
+        self._check(self._lib.vqhip_multi_decode(self._h, indices.ctypes.data, indices.shape[0], out.ctypes.data))
+        return out
 
 
 class IVQVAECodec:

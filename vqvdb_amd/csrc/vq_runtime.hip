@@ -480,9 +480,8 @@ const ActSpec kActs[] = {
     {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64},
 };
 
-int ensure_workspace(vqhip_codec* c, int64_t n_leaves, bool want_zdbg)
+int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
 {
-    (void)want_zdbg;
     const int64_t tiles = (n_leaves + 31) / 32;
     if (tiles <= c->ws_tiles) return VQHIP_OK;
     if (c->ws) {
@@ -570,9 +569,9 @@ int init_kernel_attrs(vqhip_codec* c)
     return VQHIP_OK;
 }
 
-int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, hipStream_t s, bool zdbg)
+int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, hipStream_t s)
 {
-    int rc = ensure_workspace(c, n, zdbg);
+    int rc = ensure_workspace(c, n);
     if (rc) return rc;
     const int nt = (int)((n + 31) / 32);
     auto& a = c->act;
@@ -640,7 +639,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
 
 int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, hipStream_t s)
 {
-    int rc = ensure_workspace(c, n, false);
+    int rc = ensure_workspace(c, n);
     if (rc) return rc;
     const int nt = (int)((n + 31) / 32);
     auto& a = c->act;
@@ -787,7 +786,7 @@ int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out,
         HIPCHK(c, hipEventRecord(c->ev_in[slot], c->s_in));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[slot], 0));  // slot's previous output drained to pinned
-        rc = is_encode ? encode_chunk(c, c->dev_leaves[slot], m, c->dev_idx[slot], c->stream, c->debug)
+        rc = is_encode ? encode_chunk(c, c->dev_leaves[slot], m, c->dev_idx[slot], c->stream)
                        : decode_chunk(c, c->dev_idx[slot], m, c->dev_leaves[slot], c->stream);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev_done[slot], c->stream));
@@ -911,7 +910,7 @@ int vqhip_encode_device(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int64_t m = std::min(c->chunk, n - o);
-        int rc = encode_chunk(c, d_leaves + o * 512, m, d_idx + o * 64, s, c->debug);
+        int rc = encode_chunk(c, d_leaves + o * 512, m, d_idx + o * 64, s);
         if (rc) return rc;
     }
     return VQHIP_OK;
@@ -958,6 +957,74 @@ int vqhip_decode_leaves(vqhip_codec* c, const uint8_t* indices, int64_t n, float
     if (!leaf_ptrs || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode_leaves: null pointer or n_leaves < 1");
     return run_host_pipeline(c, false, indices, nullptr, n, nullptr, leaf_ptrs);
 }
+
+// ---- in-process multi-GPU front end: one codec + one host thread per device, contiguous leaf ranges ----
+struct vqhip_multi {
+    std::vector<vqhip_codec*> dev;
+    std::string err;
+};
+
+int vqhip_multi_create(const char* pack_path, const void* pack_bytes, size_t pack_size, const int* device_ids, int n_devices, vqhip_multi** out)
+{
+    if (!out) return fail(nullptr, VQHIP_ERR_INVALID, "vqhip_multi_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1) return fail(nullptr, VQHIP_ERR_INVALID, "vqhip_multi_create: need at least one device id");
+    vqhip_multi* m = new vqhip_multi();
+    for (int i = 0; i < n_devices; ++i) {
+        vqhip_codec* c = nullptr;
+        const int rc = vqhip_create(pack_path, pack_bytes, pack_size, device_ids[i], &c);
+        if (rc != VQHIP_OK) {
+            for (vqhip_codec* d : m->dev) vqhip_destroy(d);
+            delete m;
+            return rc;  // message already in the thread-local create error
+        }
+        m->dev.push_back(c);
+    }
+    *out = m;
+    return VQHIP_OK;
+}
+
+void vqhip_multi_destroy(vqhip_multi* m)
+{
+    if (!m) return;
+    for (vqhip_codec* d : m->dev) vqhip_destroy(d);
+    delete m;
+}
+
+const char* vqhip_multi_last_error(const vqhip_multi* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+// rank g of G takes leaves [g*ceil(n/G), min(n,(g+1)*ceil(n/G))); results land at the same
+// offsets of the caller's buffer, so leaf order is preserved and there is no collective.
+static int multi_run(vqhip_multi* m, bool is_encode, const void* in, void* out, int64_t n)
+{
+    if (!m) return VQHIP_ERR_INVALID;
+    if (!in || !out || n < 1) {
+        m->err = "multi: null pointer or n_leaves < 1";
+        return VQHIP_ERR_INVALID;
+    }
+    const int G = (int)m->dev.size();
+    const int64_t per = (n + G - 1) / G;
+    std::vector<int> rcs(G, VQHIP_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        const int64_t lo = std::min(n, g * per), hi = std::min(n, lo + per);
+        if (hi == lo) continue;
+        th.emplace_back([=, &rcs] {
+            rcs[g] = is_encode ? vqhip_encode(m->dev[g], static_cast<const float*>(in) + lo * 512, hi - lo, static_cast<uint8_t*>(out) + lo * 64)
+                               : vqhip_decode(m->dev[g], static_cast<const uint8_t*>(in) + lo * 64, hi - lo, static_cast<float*>(out) + lo * 512);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g)
+        if (rcs[g] != VQHIP_OK) {
+            m->err = "device " + std::to_string(m->dev[g]->device) + ": " + m->dev[g]->err;
+            return rcs[g];
+        }
+    return VQHIP_OK;
+}
+
+int vqhip_multi_encode(vqhip_multi* m, const float* leaves, int64_t n, uint8_t* indices) { return multi_run(m, true, leaves, indices, n); }
+int vqhip_multi_decode(vqhip_multi* m, const uint8_t* indices, int64_t n, float* leaves) { return multi_run(m, false, indices, leaves, n); }
 
 int vqhip_debug_enable(vqhip_codec* c, int enable)
 {
