@@ -265,6 +265,26 @@ std::vector<int> steps_rows8()
     return t;
 }
 
+// row schedule for conv_rows32_k: one step = (output row (od,oh) of SO positions, valid (kd,kh));
+// x = input row base position, y = first tap (kw = 0) of the (kd,kh) run, z = output row base
+std::vector<int> steps_rows(int SI, int SO, int KS, int STRIDE, int PAD)
+{
+    std::vector<int> t;
+    for (int od = 0; od < SO; ++od)
+        for (int oh = 0; oh < SO; ++oh) {
+            const size_t first = t.size();
+            for (int kd = 0; kd < KS; ++kd)
+                for (int kh = 0; kh < KS; ++kh) {
+                    const int id = od * STRIDE - PAD + kd, ih = oh * STRIDE - PAD + kh;
+                    if (id < 0 || id >= SI || ih < 0 || ih >= SI) continue;
+                    t.insert(t.end(), {(id * SI + ih) * SI, (kd * KS + kh) * KS, (od * SO + oh) * SO, 1 << 8});
+                }
+            t[first + 3] |= 1;
+            t[t.size() - 1] |= 2;
+        }
+    return t;
+}
+
 // first conv: one step = (output row, valid kd); kh validity as a 3-bit mask
 std::vector<int> steps_rows8_kd()
 {
@@ -452,9 +472,9 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     }
 #undef UP
     if ((rc = upload_i(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
-    if ((rc = upload_i(c, "steps.k3s1_4g", steps_conv(4, 4, 3, 1, 1, 3)))) return rc;    // kw-runs of up to 3 taps
-    if ((rc = upload_i(c, "steps.k4s2_8g", steps_conv(8, 4, 4, 2, 1, 4)))) return rc;    // kw-runs of up to 4 taps
     if ((rc = upload_i(c, "steps.rows8", steps_rows8()))) return rc;
+    if ((rc = upload_i(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1)))) return rc;
+    if ((rc = upload_i(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1)))) return rc;
     if ((rc = upload_i(c, "steps.rows8kd", steps_rows8_kd()))) return rc;
     {
         // decoder stem as a per-(tap, code) partial-sum table (stem_lut_k), built on the device once
@@ -549,9 +569,10 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 
 // kernel instantiations -------------------------------------------------------------------
 //                                          CIN COUT NPI NPO NW STREAM KWG INMODE GIN RESID GOUT CSUM  OUTMODE
-constexpr auto k_enc_down = conv_mfma32_k<16, 32, 512, 64, 8, false, 4, 0, 0, false, 8, false, 0>;
-constexpr auto k_enc_r32c1 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false, 8, false, 0>;
-constexpr auto k_enc_r32c2 = conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true, 0, true, 0>;
+//                                        CIN COUT SI SO KS ST PD NW INMODE GIN RESID GOUT CSUM
+constexpr auto k_enc_down = conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 8, 0, 0, false, 8, false>;
+constexpr auto k_enc_r32c1 = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, false, 8, false>;
+constexpr auto k_enc_r32c2 = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, true, 0, true>;
 constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false, 8, false, 0>;
 constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true, 0, true, 0>;
 constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
@@ -609,24 +630,24 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         ConvArgs A{};
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"];
         A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k4s2_8g"], A.n_taps = 64;
-        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down, dim3(g8), dim3(512), LDS_ENC_DOWN, s, A, (const int4*)w["steps.k4s2_8g"]); });
+        A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64;
+        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down, dim3(g8), dim3(512), LDS_ENC_DOWN, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4g"], A.n_taps = 27;
-        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.k3s1_4g"]); });
+        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
+        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
         A.out_csum = a["csum"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4g"], A.n_taps = 27;
-        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.k3s1_4g"]); });
+        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
+        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         VqArgs A{};
