@@ -309,12 +309,15 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
 
 // ------------------------------------------------------------------------------------------
 // E4/E6: Conv3d(16->16,k3,p1) @8^3 inside ResidualBlock(16) (VQVAE_v2.py:190-210, :238).
-// 16x16x4 MFMA (rows 16 couts, cols 16 leaves, K = 4 channels/step, order P16); one wave owns
-// a 32-leaf tile as two 16-leaf sub-tiles and register-blocks a full row of 8 outputs so each
-// loaded input float4 feeds up to 3 taps.  Steps = (output row, valid (kd,kh)); the next step's
-// input row (16 float4 per lane) is prefetched while the current step's ~176 MFMAs issue.
-// Input transform relu(GroupNorm(8,16)) is applied once per loaded element.  Weights (27 KB)
-// stay resident in LDS.
+// 16x16x4 MFMA (rows 16 couts, cols 16 leaves, K = 4 channels/step, order P16), weights (27 KB) resident in LDS.
+// One wave owns a 16-leaf half tile and TWO adjacent output rows (oh0, oh0+1) of 8 positions each;
+// one step = (row pair, kd, input row ih in [oh0-1, oh0+2]).  An input row feeds output row A = oh0 with
+// kh = ih-oh0+1 and row B = oh0+1 with kh = ih-oh0 (whichever are valid), so 12 row loads serve two
+// output rows instead of 18, and the table has 1/3 fewer steps.  The input row lives in a single rolling
+// register buffer: transformed in place at the start of a step, each position re-loaded for the next step
+// right after its last use.  Per output, taps still arrive in ascending (kd,kh,kw) order -> same
+// arithmetic as a plain tap-by-tap evaluation.  conv2 fuses the residual `x + 0.1*y`; conv1 emits the
+// GroupNorm(8,16) statistics of its output.
 // ------------------------------------------------------------------------------------------
 template <bool RESID, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __restrict__ steps)
@@ -324,124 +327,125 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
+    const int half = blockIdx.x * 4 + wave;
+    const int tile = half >> 1;
     if (tile >= A.n_tiles) return;
-    const int jj = lane & 15, q4 = lane >> 4;
-    float ia[2][4], ib[2][4];
+    const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
+    float ia[4], ib[4];
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = 4 * q4 + i, g = c >> 1;
-            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + 16 * sb + jj];
-            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + 16 * sb + jj];
-            ia[sb][i] = rstd * A.in_gamma[c];
-            ib[sb][i] = __builtin_fmaf(-mean, ia[sb][i], A.in_beta[c]);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * q4 + i, g = c >> 1;
+        const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + jj];
+        const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + jj];
+        ia[i] = rstd * A.in_gamma[c];
+        ib[i] = __builtin_fmaf(-mean, ia[i], A.in_beta[c]);
+    }
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
     const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
-    GnAcc st[2][2];
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-        st[sb][0].init();
-        st[sb][1].init();
-    }
+    GnAcc st[2];
+    st[0].init();
+    st[1].init();
     const int NS = A.n_steps;
     int4 e = steps[0];
     int4 en = steps[1];
-    f32x4 xn[8][2];
+    f32x4 xr[8];
 #pragma unroll
-    for (int iw = 0; iw < 8; ++iw) {
-        xn[iw][0] = in4[((size_t)(e.x + iw) * 4) * 32];
-        xn[iw][1] = in4[((size_t)(e.x + iw) * 4) * 32 + 16];
-    }
+    for (int iw = 0; iw < 8; ++iw) xr[iw] = in4[((size_t)(e.x + iw) * 4) * 32];
     int si = 0;
-    for (int row = 0; row < 64; ++row) {
-        f32x4 acc[8][2];
+    for (int pr = 0; pr < 32; ++pr) {  // 8 od x 4 row pairs
+        f32x4 acc[2][8];
 #pragma unroll
-        for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
+        for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) acc[rw][ow] = (f32x4){0, 0, 0, 0};
         bool last;
         do {
-            f32x4 xc[8][2];
 #pragma unroll
-            for (int iw = 0; iw < 8; ++iw)
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    f32x4 v = xn[iw][sb];
-                    v.x = fmaxf(__builtin_fmaf(v.x, ia[sb][0], ib[sb][0]), 0.0f);
-                    v.y = fmaxf(__builtin_fmaf(v.y, ia[sb][1], ib[sb][1]), 0.0f);
-                    v.z = fmaxf(__builtin_fmaf(v.z, ia[sb][2], ib[sb][2]), 0.0f);
-                    v.w = fmaxf(__builtin_fmaf(v.w, ia[sb][3], ib[sb][3]), 0.0f);
-                    xc[iw][sb] = v;
-                }
-            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
-#pragma unroll
-            for (int iw = 0; iw < 8; ++iw) {  // unconditional: en is clamped to the last entry
-                xn[iw][0] = in4[((size_t)(en.x + iw) * 4) * 32];
-                xn[iw][1] = in4[((size_t)(en.x + iw) * 4) * 32 + 16];
+            for (int iw = 0; iw < 8; ++iw) {  // first use of the rolling buffer: waits for the loads of the previous step
+                f32x4 v = xr[iw];
+                v.x = fmaxf(__builtin_fmaf(v.x, ia[0], ib[0]), 0.0f);
+                v.y = fmaxf(__builtin_fmaf(v.y, ia[1], ib[1]), 0.0f);
+                v.z = fmaxf(__builtin_fmaf(v.z, ia[2], ib[2]), 0.0f);
+                v.w = fmaxf(__builtin_fmaf(v.w, ia[3], ib[3]), 0.0f);
+                xr[iw] = v;
             }
-            const f32x4* wt = wl + e.y * 3 * 64 + lane;   // e.y = kd*3+kh
-            const f32x4 w0 = wt[0], w1 = wt[64], w2 = wt[128];
+            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
+            // e.y = kd*3; bits 8..11: khA+1 (0 = row A not fed), bits 12..15: khB+1
+            const int kha = ((e.w >> 8) & 15) - 1, khb = ((e.w >> 12) & 15) - 1;
+            const f32x4* wa = wl + (e.y + (kha < 0 ? 0 : kha)) * 3 * 64 + lane;
+            const f32x4* wb = wl + (e.y + (khb < 0 ? 0 : khb)) * 3 * 64 + lane;
+            const f32x4 wa0 = wa[0], wa1 = wa[64], wa2 = wa[128];
+            const f32x4 wb0 = wb[0], wb1 = wb[64], wb2 = wb[128];
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow)
+            for (int iw = 0; iw < 8; ++iw) {
+                if (kha >= 0) {
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow + kw - 1;
-                    if (iw < 0 || iw > 7) continue;
-                    const f32x4 w = kw == 0 ? w0 : (kw == 1 ? w1 : w2);
-                    // two independent accumulator chains interleaved (16x16x4: 32-cycle issue, 40-cycle dependent latency)
-                    acc[ow][0] = mfma16(w.x, xc[iw][0].x, acc[ow][0]);
-                    acc[ow][1] = mfma16(w.x, xc[iw][1].x, acc[ow][1]);
-                    acc[ow][0] = mfma16(w.y, xc[iw][0].y, acc[ow][0]);
-                    acc[ow][1] = mfma16(w.y, xc[iw][1].y, acc[ow][1]);
-                    acc[ow][0] = mfma16(w.z, xc[iw][0].z, acc[ow][0]);
-                    acc[ow][1] = mfma16(w.z, xc[iw][1].z, acc[ow][1]);
-                    acc[ow][0] = mfma16(w.w, xc[iw][0].w, acc[ow][0]);
-                    acc[ow][1] = mfma16(w.w, xc[iw][1].w, acc[ow][1]);
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int ow = iw - kw + 1;
+                        if (ow < 0 || ow > 7) continue;
+                        const f32x4 w = kw == 0 ? wa0 : (kw == 1 ? wa1 : wa2);
+                        acc[0][ow] = mfma16(w.x, xr[iw].x, acc[0][ow]);
+                        acc[0][ow] = mfma16(w.y, xr[iw].y, acc[0][ow]);
+                        acc[0][ow] = mfma16(w.z, xr[iw].z, acc[0][ow]);
+                        acc[0][ow] = mfma16(w.w, xr[iw].w, acc[0][ow]);
+                    }
                 }
+                if (khb >= 0) {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int ow = iw - kw + 1;
+                        if (ow < 0 || ow > 7) continue;
+                        const f32x4 w = kw == 0 ? wb0 : (kw == 1 ? wb1 : wb2);
+                        acc[1][ow] = mfma16(w.x, xr[iw].x, acc[1][ow]);
+                        acc[1][ow] = mfma16(w.y, xr[iw].y, acc[1][ow]);
+                        acc[1][ow] = mfma16(w.z, xr[iw].z, acc[1][ow]);
+                        acc[1][ow] = mfma16(w.w, xr[iw].w, acc[1][ow]);
+                    }
+                }
+                xr[iw] = in4[((size_t)(en.x + iw) * 4) * 32];  // next step's row (table index clamped)
+            }
             last = (e.w & 2) != 0;
             e = en;
             en = en2;
             ++si;
         } while (!last);
-        f32x4 sk[RESID ? 8 : 1][2];
-        if (RESID) {  // issue all residual loads before any of the epilogue math
+        // epilogue: rows A then B (positions ascending)
+        const int obase = (pr >> 2) * 64 + (pr & 3) * 16;  // (od*8 + oh0)*8
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow)
+        for (int rw = 0; rw < 2; ++rw) {
+            f32x4 sk[RESID ? 8 : 1];
+            if (RESID) {
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb) sk[ow][sb] = skip4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb];
-        }
+                for (int ow = 0; ow < 8; ++ow) sk[ow] = skip4[((size_t)(obase + rw * 8 + ow) * 4) * 32];
+            }
 #pragma unroll
-        for (int ow = 0; ow < 8; ++ow)
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const size_t o = ((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb;
-                f32x4 v = acc[ow][sb] + bias4;
+            for (int ow = 0; ow < 8; ++ow) {
+                const size_t o = ((size_t)(obase + rw * 8 + ow) * 4) * 32;
+                f32x4 v = acc[rw][ow] + bias4;
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
-                    v = sk[ow][sb] + u;
+                    v = sk[ow] + u;
                 }
                 out4[o] = v;
                 if (STATS) {
-                    st[sb][0].add(v.x);
-                    st[sb][0].add(v.y);
-                    st[sb][1].add(v.z);
-                    st[sb][1].add(v.w);
+                    st[0].add(v.x);
+                    st[0].add(v.y);
+                    st[1].add(v.z);
+                    st[1].add(v.w);
                 }
             }
+        }
     }
     if (STATS) {
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float m, r;
-                gn_finish(st[sb][k].s, st[sb][k].q, 1.0 / 1024.0, m, r);
-                A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * sb + jj] = m;
-                A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + 16 * sb + jj] = r;
-            }
+        for (int k = 0; k < 2; ++k) {
+            float m, r;
+            gn_finish(st[k].s, st[k].q, 1.0 / 1024.0, m, r);
+            A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + jj] = m;
+            A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + jj] = r;
+        }
     }
 }
 
