@@ -113,7 +113,7 @@ def cpu_baseline():
     W = synth.make_weights(0)
     orc = Oracle(W, [t[0] for t in synth.TENSORS])
     threads = usable_cpus()
-    n = max(1024, min(16384, 64 * threads))
+    n = max(4096, min(16384, 256 * threads))
     leaves = synth.make_leaves(n, seed=1234)
 
     def leg(fn, arg, budget=10.0):
