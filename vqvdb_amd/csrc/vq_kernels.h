@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
 // ------------------------------------------------------------------------------------------
 // E4/E6: Conv3d(16->16,k3,p1) @8^3 inside ResidualBlock(16) (VQVAE_v2.py:190-210, :238).
 // 16x16x4 MFMA (rows 16 couts, cols 16 leaves, K = 4 channels/step, order P16), weights (27 KB) resident in LDS.
-// One wave owns a 16-leaf half tile and TWO adjacent output rows (oh0, oh0+1) of 8 positions each;
-// one step = (row pair, kd, input row ih in [oh0-1, oh0+2]).  An input row feeds output row A = oh0 with
+// One wave owns a 16-leaf half tile and NR (2 or 4) adjacent output rows of 8 positions each;
+// one step = (row group, kd, input row ih in [oh0-1, oh0+NR]).  An input row feeds output row A = oh0 with
 // kh = ih-oh0+1 and row B = oh0+1 with kh = ih-oh0 (whichever are valid), so 12 row loads serve two
 // output rows instead of 18, and the table has 1/3 fewer steps.  The input row lives in a single rolling
 // register buffer: transformed in place at the start of a step, each position re-loaded for the next step
@@ -319,9 +319,10 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
 // arithmetic as a plain tap-by-tap evaluation.  conv2 fuses the residual `x + 0.1*y`; conv1 emits the
 // GroupNorm(8,16) statistics of its output.
 // ------------------------------------------------------------------------------------------
-template <bool RESID, bool STATS>
+template <int NR, bool RESID, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __restrict__ steps)
 {
+    static_assert(NR == 2 || NR == 4, "output rows per wave");
     __shared__ f32x4 wl[27 * 64];
     for (int i = threadIdx.x; i < 27 * 64; i += 256) wl[i] = ((const f32x4*)A.wfrag)[i];
     __syncthreads();
@@ -354,10 +355,10 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
 #pragma unroll
     for (int iw = 0; iw < 8; ++iw) xr[iw] = in4[((size_t)(e.x + iw) * 4) * 32];
     int si = 0;
-    for (int pr = 0; pr < 32; ++pr) {  // 8 od x 4 row pairs
-        f32x4 acc[2][8];
+    for (int grp = 0; grp < 64 / NR; ++grp) {  // 8 od x (8/NR) row groups
+        f32x4 acc[NR][8];
 #pragma unroll
-        for (int rw = 0; rw < 2; ++rw)
+        for (int rw = 0; rw < NR; ++rw)
 #pragma unroll
             for (int ow = 0; ow < 8; ++ow) acc[rw][ow] = (f32x4){0, 0, 0, 0};
         bool last;
@@ -372,36 +373,29 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                 xr[iw] = v;
             }
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
-            // e.y = kd*3; bits 8..11: khA+1 (0 = row A not fed), bits 12..15: khB+1
-            const int kha = ((e.w >> 8) & 15) - 1, khb = ((e.w >> 12) & 15) - 1;
-            const f32x4* wa = wl + (e.y + (kha < 0 ? 0 : kha)) * 3 * 64 + lane;
-            const f32x4* wb = wl + (e.y + (khb < 0 ? 0 : khb)) * 3 * 64 + lane;
-            const f32x4 wa0 = wa[0], wa1 = wa[64], wa2 = wa[128];
-            const f32x4 wb0 = wb[0], wb1 = wb[64], wb2 = wb[128];
+            // e.y = kd*3; bits 8+4*rw .. : kh+1 of output row rw of the group (0 = this input row does not feed it)
+            int kh[NR];
+            f32x4 w[NR][3];
+#pragma unroll
+            for (int rw = 0; rw < NR; ++rw) {
+                kh[rw] = ((e.w >> (8 + 4 * rw)) & 15) - 1;
+                const f32x4* wp = wl + (e.y + (kh[rw] < 0 ? 0 : kh[rw])) * 3 * 64 + lane;
+                w[rw][0] = wp[0], w[rw][1] = wp[64], w[rw][2] = wp[128];
+            }
 #pragma unroll
             for (int iw = 0; iw < 8; ++iw) {
-                if (kha >= 0) {
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int ow = iw - kw + 1;
-                        if (ow < 0 || ow > 7) continue;
-                        const f32x4 w = kw == 0 ? wa0 : (kw == 1 ? wa1 : wa2);
-                        acc[0][ow] = mfma16(w.x, xr[iw].x, acc[0][ow]);
-                        acc[0][ow] = mfma16(w.y, xr[iw].y, acc[0][ow]);
-                        acc[0][ow] = mfma16(w.z, xr[iw].z, acc[0][ow]);
-                        acc[0][ow] = mfma16(w.w, xr[iw].w, acc[0][ow]);
-                    }
-                }
-                if (khb >= 0) {
+                for (int rw = 0; rw < NR; ++rw) {
+                    if (kh[rw] >= 0) {
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int ow = iw - kw + 1;
-                        if (ow < 0 || ow > 7) continue;
-                        const f32x4 w = kw == 0 ? wb0 : (kw == 1 ? wb1 : wb2);
-                        acc[1][ow] = mfma16(w.x, xr[iw].x, acc[1][ow]);
-                        acc[1][ow] = mfma16(w.y, xr[iw].y, acc[1][ow]);
-                        acc[1][ow] = mfma16(w.z, xr[iw].z, acc[1][ow]);
-                        acc[1][ow] = mfma16(w.w, xr[iw].w, acc[1][ow]);
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int ow = iw - kw + 1;
+                            if (ow < 0 || ow > 7) continue;
+                            acc[rw][ow] = mfma16(w[rw][kw].x, xr[iw].x, acc[rw][ow]);
+                            acc[rw][ow] = mfma16(w[rw][kw].y, xr[iw].y, acc[rw][ow]);
+                            acc[rw][ow] = mfma16(w[rw][kw].z, xr[iw].z, acc[rw][ow]);
+                            acc[rw][ow] = mfma16(w[rw][kw].w, xr[iw].w, acc[rw][ow]);
+                        }
                     }
                 }
                 xr[iw] = in4[((size_t)(en.x + iw) * 4) * 32];  // next step's row (table index clamped)
@@ -411,10 +405,10 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
             en = en2;
             ++si;
         } while (!last);
-        // epilogue: rows A then B (positions ascending)
-        const int obase = (pr >> 2) * 64 + (pr & 3) * 16;  // (od*8 + oh0)*8
+        // epilogue: the NR rows in order (positions ascending)
+        const int obase = grp * NR * 8;  // (od*8 + oh0)*8: groups tile the 64 rows in order
 #pragma unroll
-        for (int rw = 0; rw < 2; ++rw) {
+        for (int rw = 0; rw < NR; ++rw) {
             f32x4 sk[RESID ? 8 : 1];
             if (RESID) {
 #pragma unroll

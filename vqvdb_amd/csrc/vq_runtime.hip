@@ -266,23 +266,26 @@ std::vector<int> steps_rows(int SI, int SO, int KS, int STRIDE, int PAD)
     return t;
 }
 
-// conv8_c16r2_k: one step = (od, output row pair oh0 = 2p, valid kd, input row ih in [oh0-1, oh0+2]);
-// w bits 8..11 = khA+1 (row oh0), bits 12..15 = khB+1 (row oh0+1), 0 = that row is not fed by this input row
-std::vector<int> steps_rowpairs8()
+// conv8_c16_k<NR>: one step = (od, output row group oh0 = NR*g, valid kd, input row ih in [oh0-1, oh0+NR]);
+// w bits 8+4*rw.. = kh+1 of output row oh0+rw (0 = that row is not fed by this input row)
+std::vector<int> steps_rowgroups8(int NR)
 {
     std::vector<int> t;
     for (int od = 0; od < 8; ++od)
-        for (int p = 0; p < 4; ++p) {
-            const int oh0 = 2 * p;
+        for (int g = 0; g < 8 / NR; ++g) {
+            const int oh0 = NR * g;
             const size_t first = t.size();
             for (int kd = 0; kd < 3; ++kd) {
                 const int id = od + kd - 1;
                 if (id < 0 || id > 7) continue;
-                for (int ih = oh0 - 1; ih <= oh0 + 2; ++ih) {
+                for (int ih = oh0 - 1; ih <= oh0 + NR; ++ih) {
                     if (ih < 0 || ih > 7) continue;
-                    const int kha = ih - oh0 + 1, khb = ih - oh0;
-                    const int fa = (kha >= 0 && kha <= 2) ? kha + 1 : 0, fb = (khb >= 0 && khb <= 2) ? khb + 1 : 0;
-                    t.insert(t.end(), {(id * 8 + ih) * 8, kd * 3, (od * 8 + oh0) * 8, (fa << 8) | (fb << 12)});
+                    int feeds = 0;
+                    for (int rw = 0; rw < NR; ++rw) {
+                        const int kh = ih - (oh0 + rw) + 1;
+                        if (kh >= 0 && kh <= 2) feeds |= (kh + 1) << (8 + 4 * rw);
+                    }
+                    t.insert(t.end(), {(id * 8 + ih) * 8, kd * 3, (od * 8 + oh0) * 8, feeds});
                 }
             }
             t[first + 3] |= 1;
@@ -478,7 +481,7 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     }
 #undef UP
     if ((rc = upload_i(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
-    if ((rc = upload_i(c, "steps.rowpairs8", steps_rowpairs8()))) return rc;
+    if ((rc = upload_i(c, "steps.rowgroups8_4", steps_rowgroups8(4)))) return rc;
     if ((rc = upload_i(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1)))) return rc;
     if ((rc = upload_i(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1)))) return rc;
     if ((rc = upload_i(c, "steps.rows8kd", steps_rows8_kd()))) return rc;
@@ -622,15 +625,15 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rowpairs8"];
-        L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<false, true>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowpairs8"]); });
+        A.n_steps = c->nsteps["steps.rowgroups8_4"];
+        L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rowpairs8"];
-        L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<true, false>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowpairs8"]); });
+        A.n_steps = c->nsteps["steps.rowgroups8_4"];
+        L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
     }
     {
         ConvArgs A{};
