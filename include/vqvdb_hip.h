@@ -82,6 +82,48 @@ int vqhip_decode_device(vqhip_codec* codec, const uint8_t* indices_dev, int64_t 
 int vqhip_encode_leaves(vqhip_codec* codec, const float* const* leaf_ptrs, int64_t n_leaves, uint8_t* indices);
 int vqhip_decode_leaves(vqhip_codec* codec, const uint8_t* indices, int64_t n_leaves, float* const* leaf_ptrs);
 
+/* ---- .vqvdb stream entry points (extension) -------------------------------------------
+ * Whole-file compress / decompress with file I/O, GPU work and leaf insertion overlapped: the MI355X-native
+ * replacement for the bodies of VQVAECodec::compress (src/orchestrator/VQVAECodec.cpp:78-134) and
+ * VQVAECodec::decompress (:137-208), and of the record framing in VQVDB_Writer::writeBatch /
+ * VQVDB_Reader::nextBatch (src/Utils/VQVDB_Reader.cpp:137-150,240-300).  File layout: .vqvdb v3, 76-byte
+ * {int32 origin[3], uint8 indices[64]} records.  No OpenVDB types cross the ABI: the
+ * caller creates grids/leaves in its callbacks and hands back plain float pointers. */
+typedef struct vqhip_grid_info {
+    const char* name;          /* NUL-terminated, valid during the callback only */
+    float transform[16];       /* Mat4s as stored                                 */
+    int64_t latent_shape[3];   /* {4,4,4}                                         */
+    uint32_t num_embeddings;   /* header field (256)                              */
+    uint64_t total_blocks;     /* leaves in this grid                             */
+    int grid_index;
+} vqhip_grid_info;
+/* Called on the calling thread once per grid, before its leaves (create the grid, set name/transform). !=0 aborts. */
+typedef int (*vqhip_grid_begin_fn)(void* user, const vqhip_grid_info* grid);
+/* Called once per batch, in file order, from ONE library thread while the GPU decodes earlier batches: create
+ * or look up the n leaves at origins[n][3] (e.g. tree.touchLeaf) and store where each leaf's 512 floats go
+ * (leaf.buffer().data()).  The library fills them before vqhip_decompress_file returns.  !=0 aborts. */
+typedef int (*vqhip_leaf_alloc_fn)(void* user, int grid_index, const int32_t* origins, int64_t n_leaves, float** leaf_ptrs);
+typedef struct vqhip_stream_stats {
+    int64_t leaves;
+    int32_t grids;
+    double wall_s;     /* whole call                                                             */
+    double read_s;     /* file read/write + record (de)framing                                   */
+    double alloc_s;    /* time inside leaf_alloc callbacks (reader thread)                       */
+    double copy_s;     /* gather / scatter between leaf buffers and pinned staging               */
+    double io_wait_s;  /* time the pipeline waited for the reader thread (0 = GPU-bound)         */
+} vqhip_stream_stats;
+int vqhip_decompress_file(vqhip_codec* codec, const char* path, int64_t batch_leaves, vqhip_grid_begin_fn grid_begin,
+                          vqhip_leaf_alloc_fn leaf_alloc, void* user, vqhip_stream_stats* stats);
+typedef struct vqhip_grid_source {
+    const char* name;
+    const float* transform;          /* 16 floats, NULL = identity              */
+    const float* const* leaf_ptrs;   /* n_leaves pointers to 512 floats each    */
+    const int32_t* origins;          /* [n_leaves][3]                           */
+    int64_t n_leaves;                /* < 2^32 (file field is u32)              */
+} vqhip_grid_source;
+int vqhip_compress_file(vqhip_codec* codec, const char* path, const vqhip_grid_source* grids, int n_grids, int64_t batch_leaves,
+                        vqhip_stream_stats* stats);
+
 /* In-process multi-GPU front end (extension): one codec and one host thread per listed
  * device, device g of G takes the contiguous leaf range [g*ceil(n/G), min(n,(g+1)*ceil(n/G))) of every call
  * and writes to the same offsets of the caller's buffer.  Weights are replicated; there is no collective.
@@ -96,6 +138,12 @@ int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_lea
 /* Leaves processed per internal pass (default 65536).  Bounds the device workspace
  * (about 0.26 MB per leaf). */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
+
+/* Allocates up front what calls of up to n_leaves leaves (capped at the chunk size) need: the device workspace,
+ * the device I/O slots and the pinned staging buffers.  Optional — every entry point allocates lazily — but it
+ * moves the one-time cost (hundreds of ms for a 65536-leaf chunk: ~17 GB of HBM, 0.5 GB pinned) out of the first
+ * cook, the way the reference backends pay model loading in IVQVAECodec::create. */
+int vqhip_reserve(vqhip_codec* codec, int64_t n_leaves);
 
 /* ---- measurement hooks (bench.py / tests) ---- */
 

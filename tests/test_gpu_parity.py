@@ -179,6 +179,79 @@ def test_cpp_adapter_orchestrator_roundtrip(codec, pack, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def _origins(n, start=0):
+    i = np.arange(start, start + n, dtype=np.int64)
+    return np.stack([8 * (i % 1024), 8 * ((i // 1024) % 1024), 8 * (i // 1048576)], axis=1).astype(np.int32)
+
+
+def test_stream_file_entry_points_match_block_path(codec, tmp_path):
+    """vqhip_compress_file / vqhip_decompress_file (file I/O || GPU || leaf insert overlapped inside the library)
+    produce byte-for-byte the .vqvdb the block path + host framing produces, and the same voxels; multi-grid,
+    ragged last batch, per-leaf buffers, empty grid."""
+    from vqvdb_amd import vqvdbfile
+    la, lb = synth.make_leaves(10000, seed=5), synth.make_leaves(333, seed=6)
+    oa, ob = _origins(10000), _origins(333, start=5_000_000)
+    tr = np.arange(16, dtype=np.float32) * 0.25
+    ia, ib = codec.encode(la), codec.encode(lb)
+    want = vqvdbfile.dumps([vqvdbfile.Grid("density", oa, ia), vqvdbfile.Grid("temperature", ob, ib, tr),
+                            vqvdbfile.Grid("empty", np.zeros((0, 3), np.int32), np.zeros((0, 64), np.uint8))])
+    path = tmp_path / "s.vqvdb"
+    for batch in (0, 4096, 1000):
+        st = codec.compress_file(path, [("density", oa, la, None), ("temperature", ob, [lb[i].copy() for i in range(333)], tr),
+                                        ("empty", np.zeros((0, 3), np.int32), np.zeros((0, 512), np.float32), None)], batch_leaves=batch)
+        assert st["leaves"] == 10333 and st["grids"] == 3
+        assert path.read_bytes() == want
+        grids, st = codec.decompress_file(path, batch_leaves=batch)
+        assert st["leaves"] == 10333 and [g[0] for g in grids] == ["density", "temperature", "empty"]
+        assert np.array_equal(grids[1][1], tr) and np.array_equal(grids[0][1], np.eye(4, dtype=np.float32).reshape(16))
+        assert np.array_equal(grids[0][2], oa) and np.array_equal(grids[1][2], ob) and len(grids[2][2]) == 0
+        assert np.array_equal(_bits(grids[0][3]), _bits(codec.decode(ia)))
+        assert np.array_equal(_bits(grids[1][3]), _bits(codec.decode(ib)))
+
+
+def test_stream_file_errors_fail_loudly(codec, tmp_path):
+    from vqvdb_amd import vqvdbfile
+    idx = codec.encode(synth.make_leaves(100, seed=9))
+    good = vqvdbfile.dumps([vqvdbfile.Grid("density", _origins(100), idx)])
+    cases = {"trunc": (good[:-30], "File truncated"), "magic": (b"NOTVQ" + good[5:], "Invalid file magic"),
+             "version": (good[:5] + b"\x02" + good[6:], "Unsupported .vqvdb version"),
+             "shape": (good[:12 + 4 + 7 + 64] + b"\x08\x00\x08\x00\x08\x00" + good[12 + 4 + 7 + 64 + 6:], "latent shape"),
+             "header": (good[:7], "Failed to read file header")}
+    for name, (blob, msg) in cases.items():
+        p = tmp_path / f"{name}.vqvdb"
+        p.write_bytes(blob)
+        with pytest.raises(RuntimeError, match=msg):
+            codec.decompress_file(p)
+    with pytest.raises(RuntimeError, match="Cannot open input file"):
+        codec.decompress_file(tmp_path / "missing.vqvdb")
+    with pytest.raises(RuntimeError, match="Cannot open output file"):
+        codec.compress_file(tmp_path / "no_such_dir" / "x.vqvdb", [("g", _origins(1), synth.make_leaves(1), None)])
+    with pytest.raises(RuntimeError, match="1..255 grids"):
+        codec.compress_file(tmp_path / "x.vqvdb", [])
+    # the codec is still usable after every failure
+    assert np.array_equal(codec.encode(synth.make_leaves(100, seed=9)), idx)
+
+
+def test_cpp_harness_stream_modes_match_orchestrator_modes(codec, pack, tmp_path):
+    """leaf_harness compress_stream / decompress_stream (C ABI whole-file entry points, hash-map leaf store standing in
+    for tree.touchLeaf) write the same files as the orchestrator-shaped compress / decompress modes."""
+    import subprocess
+    from vqvdb_amd.build import HARNESS
+    leaves = synth.make_leaves(5000, seed=33)
+    (tmp_path / "m.vqw").write_bytes(pack)
+    leaves.tofile(tmp_path / "in.f32")
+    m, i = str(tmp_path / "m.vqw"), str(tmp_path / "in.f32")
+    for mode, out in (("compress", "a.vqvdb"), ("compress_stream", "b.vqvdb")):
+        r = subprocess.run([HARNESS, mode, m, i, str(tmp_path / out), "2048"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert (tmp_path / "a.vqvdb").read_bytes() == (tmp_path / "b.vqvdb").read_bytes()
+    for mode, out in (("decompress", "a.f32"), ("decompress_stream", "b.f32")):
+        r = subprocess.run([HARNESS, mode, m, str(tmp_path / "a.vqvdb"), str(tmp_path / out), "2048"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert (tmp_path / "a.f32").read_bytes() == (tmp_path / "b.f32").read_bytes()
+    assert np.array_equal(_bits(np.fromfile(tmp_path / "b.f32", dtype=np.float32).reshape(5000, 512)), _bits(codec.decode(codec.encode(leaves))))
+
+
 def test_config1_10k_random_leaves_roundtrip(codec, oracle):
     """BASELINE configs[0] size: 10 000 random leaves, K=256 D=128, encode -> indices -> decode, every
     index and every voxel compared with the CPU oracle."""

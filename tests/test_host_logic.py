@@ -88,3 +88,26 @@ def test_vqvdb_stream_framing_roundtrip(tmp_path):
         assert (x, y, z) == (8 * (total % 1024), 8 * ((total // 1024) % 1024), 0)
         off += nb * 76; total += nb
     assert off == len(raw) and total == 1000
+
+
+def test_vqvdbfile_numpy_matches_cpp_writer(tmp_path):
+    """vqvdb_amd/vqvdbfile.py (numpy framing used by the stream parity tests) parses the file the C++ writer
+    produced and re-serialises it to the same bytes; truncated / foreign files are rejected with the reader's messages."""
+    import subprocess
+    from vqvdb_amd import vqvdbfile
+    from vqvdb_amd.build import build, build_harness
+    build()
+    exe = build_harness()
+    path = tmp_path / "t.vqvdb"
+    assert subprocess.run([exe, "streamtest", str(path)], capture_output=True).returncode == 0
+    raw = path.read_bytes()
+    grids = vqvdbfile.loads(raw)
+    assert [g.name for g in grids] == ["density", "temperature"] and [len(g.origins) for g in grids] == [700, 300]
+    assert grids[1].transform[0] == 1.5 and grids[0].indices.dtype == np.uint8
+    assert vqvdbfile.dumps(grids) == raw
+    with pytest.raises(ValueError, match="truncated"):
+        vqvdbfile.loads(raw[:-10])
+    with pytest.raises(ValueError, match="magic"):
+        vqvdbfile.loads(b"OPENVDB" + raw[7:])
+    empty = [vqvdbfile.Grid("e", np.zeros((0, 3), np.int32), np.zeros((0, 64), np.uint8))]
+    assert len(vqvdbfile.loads(vqvdbfile.dumps(empty))[0].origins) == 0

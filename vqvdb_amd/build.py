@@ -49,7 +49,8 @@ def build_harness(force: bool = False) -> str:
     """C++ host side: IVQVAECodec adapter + factory + orchestrator-style harness (g++, links the C ABI)."""
     srcs = [os.path.join(HERE, "host", f) for f in ("leaf_harness.cpp", "codec_factory.cpp")]
     deps = srcs + [os.path.join(HERE, "host", "vqvdb_stream.hpp"), os.path.join(HERE, "host", "codec_interface.hpp"),
-                   os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip_backend.hpp")]
+                   os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip_backend.hpp"),
+                   os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip.h")]
     if force or not os.path.exists(HARNESS) or any(os.path.getmtime(d) > os.path.getmtime(HARNESS) for d in deps):
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", HARNESS, *srcs, "-L" + HERE, "-lvqvdb_hip", "-Wl,-rpath,$ORIGIN/.."]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -88,7 +88,31 @@ ABI_SYMBOLS = [
     "vqhip_encode_device", "vqhip_decode_device", "vqhip_encode_leaves", "vqhip_decode_leaves", "vqhip_set_chunk_leaves", "vqhip_profile_enable",
     "vqhip_profile_read", "vqhip_debug_enable", "vqhip_debug_fetch", "vqhip_selftest_mfma", "vqhip_version",
     "vqhip_multi_create", "vqhip_multi_destroy", "vqhip_multi_last_error", "vqhip_multi_encode", "vqhip_multi_decode",
+    "vqhip_decompress_file", "vqhip_compress_file", "vqhip_reserve",
 ]
+
+class _GridInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("transform", ctypes.c_float * 16), ("latent_shape", ctypes.c_int64 * 3),
+                ("num_embeddings", ctypes.c_uint32), ("total_blocks", ctypes.c_uint64), ("grid_index", ctypes.c_int)]
+
+
+class StreamStats(ctypes.Structure):
+    """vqhip_stream_stats: where a whole-file compress/decompress spent its time."""
+    _fields_ = [("leaves", ctypes.c_int64), ("grids", ctypes.c_int32), ("wall_s", ctypes.c_double), ("read_s", ctypes.c_double),
+                ("alloc_s", ctypes.c_double), ("copy_s", ctypes.c_double), ("io_wait_s", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class _GridSource(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("transform", ctypes.POINTER(ctypes.c_float)), ("leaf_ptrs", ctypes.c_void_p),
+                ("origins", ctypes.c_void_p), ("n_leaves", ctypes.c_int64)]
+
+
+GRID_BEGIN_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(_GridInfo))
+LEAF_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
+                                 ctypes.POINTER(ctypes.c_void_p))
 
 _lib = None
 
@@ -115,6 +139,7 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_encode_leaves.argtypes = [vp, vp, i64, vp]
     lib.vqhip_decode_leaves.argtypes = [vp, vp, i64, vp]
     lib.vqhip_set_chunk_leaves.argtypes = [vp, i64]
+    lib.vqhip_reserve.argtypes = [vp, i64]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
     lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
     lib.vqhip_debug_enable.argtypes = [vp, ci]
@@ -128,6 +153,8 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_multi_last_error.restype = ctypes.c_char_p
     lib.vqhip_multi_encode.argtypes = [vp, vp, i64, vp]
     lib.vqhip_multi_decode.argtypes = [vp, vp, i64, vp]
+    lib.vqhip_decompress_file.argtypes = [vp, ctypes.c_char_p, i64, GRID_BEGIN_FN, LEAF_ALLOC_FN, vp, ctypes.POINTER(StreamStats)]
+    lib.vqhip_compress_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(_GridSource), ci, i64, ctypes.POINTER(StreamStats)]
     for name in ABI_SYMBOLS:
         if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error"):
             getattr(lib, name).restype = ci
@@ -165,15 +192,23 @@ class HipCodec:
         self._check(self._lib.vqhip_latent_shape(self._h, out))
         return list(out)
 
-    def encode(self, leaves: np.ndarray) -> np.ndarray:
+    @staticmethod
+    def _out(out, shape, dtype):
+        if out is None:
+            return np.empty(shape, dtype=dtype)
+        if out.dtype != dtype or out.size != shape[0] * shape[1] or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of {shape[0] * shape[1]} elements")
+        return out
+
+    def encode(self, leaves: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
         leaves = np.ascontiguousarray(leaves, dtype=np.float32).reshape(-1, LEAF_VOXELS)
-        idx = np.empty((leaves.shape[0], LATENT_VOXELS), dtype=np.uint8)
+        idx = self._out(out, (leaves.shape[0], LATENT_VOXELS), np.uint8)
         self._check(self._lib.vqhip_encode(self._h, leaves.ctypes.data, leaves.shape[0], idx.ctypes.data))
         return idx
 
-    def decode(self, indices: np.ndarray) -> np.ndarray:
+    def decode(self, indices: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
         indices = np.ascontiguousarray(indices, dtype=np.uint8).reshape(-1, LATENT_VOXELS)
-        out = np.empty((indices.shape[0], LEAF_VOXELS), dtype=np.float32)
+        out = self._out(out, (indices.shape[0], LEAF_VOXELS), np.float32)
         self._check(self._lib.vqhip_decode(self._h, indices.ctypes.data, indices.shape[0], out.ctypes.data))
         return out
 
@@ -191,6 +226,68 @@ class HipCodec:
         ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in leaf_arrays])
         self._check(self._lib.vqhip_decode_leaves(self._h, indices.ctypes.data, n, ptrs))
 
+    def compress_file(self, path, grids, batch_leaves: int = 0) -> dict:
+        """Whole-file compress (vqhip_compress_file).  grids: sequence of (name, origins int32 [n,3], leaves float32 [n,512]
+        or a list of n 512-float arrays, transform or None).  Returns the stream statistics."""
+        n_g = len(grids)
+        src = (_GridSource * max(n_g, 1))()
+        keep = []
+        for i, (name, origins, leaves, transform) in enumerate(grids):
+            origins = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)
+            n = origins.shape[0]
+            if isinstance(leaves, np.ndarray):
+                leaves = np.ascontiguousarray(leaves, dtype=np.float32).reshape(n, LEAF_VOXELS)
+                ptrs = leaves.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(LEAF_VOXELS * 4)
+            else:
+                if len(leaves) != n:
+                    raise ValueError("one leaf buffer per origin")
+                ptrs = np.array([a.ctypes.data for a in leaves], dtype=np.uint64)
+            ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
+            tr = None if transform is None else np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
+            bname = name.encode()
+            keep += [origins, leaves, ptrs, tr, bname]
+            src[i].name = bname
+            src[i].transform = tr.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if tr is not None else None
+            src[i].leaf_ptrs = ptrs.ctypes.data if n else None
+            src[i].origins = origins.ctypes.data if n else None
+            src[i].n_leaves = n
+        st = StreamStats()
+        self._check(self._lib.vqhip_compress_file(self._h, os.fspath(path).encode(), src, n_g, batch_leaves, ctypes.byref(st)))
+        return st.as_dict()
+
+    def decompress_file(self, path, batch_leaves: int = 0):
+        """Whole-file decompress (vqhip_decompress_file).  Returns ([(name, transform[16], origins [n,3], leaves [n,512])], stats);
+        the leaf allocator hands out one fresh 2 KiB-per-leaf block per batch, the stand-in for tree.touchLeaf()."""
+        grids, blocks = [], []
+
+        def on_grid(_user, gi):
+            g = gi.contents
+            grids.append([g.name.decode(), np.array(g.transform[:], dtype=np.float32), int(g.total_blocks)])
+            blocks.append([])
+            return 0
+
+        def on_alloc(_user, gidx, origins, n, out_ptrs):
+            try:
+                org = np.ctypeslib.as_array(origins, shape=(n, 3)).copy()
+                buf = np.empty((n, LEAF_VOXELS), dtype=np.float32)
+                dst = np.ctypeslib.as_array(ctypes.cast(out_ptrs, ctypes.POINTER(ctypes.c_uint64)), shape=(n,))
+                dst[:] = buf.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(LEAF_VOXELS * 4)
+                blocks[gidx].append((org, buf))
+                return 0
+            except Exception as e:  # noqa: BLE001 — an exception must not unwind through the C frames
+                print(f"decompress_file allocator: {e}", file=sys.stderr)
+                return 1
+
+        cb_g, cb_a = GRID_BEGIN_FN(on_grid), LEAF_ALLOC_FN(on_alloc)
+        st = StreamStats()
+        self._check(self._lib.vqhip_decompress_file(self._h, os.fspath(path).encode(), batch_leaves, cb_g, cb_a, None, ctypes.byref(st)))
+        out = []
+        for (name, tr, _total), bl in zip(grids, blocks):
+            org = np.concatenate([b[0] for b in bl]) if bl else np.zeros((0, 3), np.int32)
+            lv = np.concatenate([b[1] for b in bl]) if bl else np.zeros((0, LEAF_VOXELS), np.float32)
+            out.append((name, tr, org, lv))
+        return out, st.as_dict()
+
     def encode_device(self, leaves_ptr: int, n: int, idx_ptr: int, stream: int = 0):
         self._check(self._lib.vqhip_encode_device(self._h, leaves_ptr, n, idx_ptr, stream or None))
 
@@ -199,6 +296,9 @@ class HipCodec:
 
     def set_chunk_leaves(self, n: int):
         self._check(self._lib.vqhip_set_chunk_leaves(self._h, n))
+
+    def reserve(self, n: int):
+        self._check(self._lib.vqhip_reserve(self._h, n))
 
     def profile_enable(self, on: bool):
         self._check(self._lib.vqhip_profile_enable(self._h, int(on)))

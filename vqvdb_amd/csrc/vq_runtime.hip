@@ -7,10 +7,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -741,12 +746,26 @@ int ensure_io(vqhip_codec* c, int64_t n)
     return VQHIP_OK;
 }
 
+// pinned input staging (leaf blocks: gathered leaf buffers or the caller's pageable block)
+int ensure_stage(vqhip_codec* c, int64_t n)
+{
+    if (c->pin_in_leaves >= n) return VQHIP_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
+        c->pin_in[i] = nullptr;
+    }
+    c->pin_in_leaves = 0;
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc(&c->pin_in[i], (size_t)n * 2048, hipHostMallocDefault));
+    c->pin_in_leaves = n;
+    return VQHIP_OK;
+}
+
 // parallel-for over [0,n) on host threads (the library's stand-in for the orchestrator's tbb::parallel_for)
 template <typename F>
-void host_parallel_for(int64_t n, F&& f)
+void host_parallel_for(int64_t n, F&& f, int64_t grain = 2048)
 {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw / 2, (int64_t)16, n / 2048}));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw / 2, (int64_t)16, n / grain}));
     if (nt <= 1) {
         f(0, n);
         return;
@@ -757,79 +776,144 @@ void host_parallel_for(int64_t n, F&& f)
     for (auto& x : th) x.join();
 }
 
-// Host-pointer pipeline (the path the reference orchestrator calls, VQVAECodec.cpp:120,178).
-// Chunk i: H2D on s_in -> kernels on the compute stream -> D2H into pinned memory on s_out; the host
-// thread copies chunk i-1's result to the caller while the GPU works on chunk i.  encode: in = leaves
-// (2048 B/leaf), out = indices (64 B/leaf); decode: the reverse.
-// in_ptrs / out_ptrs (leaf-pointer entry points): per-leaf buffers instead of one contiguous block.
-int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out, int64_t n, const float* const* in_ptrs = nullptr,
-                      float* const* out_ptrs = nullptr)
+// multi-threaded memcpy for the large host-side block copies (pageable <-> pinned staging): one thread tops out
+// near 10 GB/s, below both the PCIe link and the kernels' leaf rate
+void host_parallel_copy(void* dst, const void* src, size_t bytes)
+{
+    constexpr size_t BLK = size_t(1) << 20;
+    const int64_t nb = (int64_t)((bytes + BLK - 1) / BLK);
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    host_parallel_for(nb, [=](int64_t a, int64_t b) {
+        const size_t lo = (size_t)a * BLK, hi = std::min(bytes, (size_t)b * BLK);
+        if (hi > lo) std::memcpy(d + lo, s + lo, hi - lo);
+    }, 4);
+}
+
+// Host-side pipeline shared by every entry point that takes host memory (the path the reference orchestrator
+// calls, VQVAECodec.cpp:120,178).  Chunk i: produce() -> H2D on s_in -> kernels on the compute stream -> D2H into
+// pinned memory on s_out; consume() of chunk i-1 runs on the calling thread while the GPU works on chunk i.
+// encode: in = leaves (2048 B/leaf), out = indices (64 B/leaf); decode: the reverse.
+//   produce(o, m, stage): returns the host address of chunk [o, o+m)'s input; `stage` is this slot's pinned
+//                         buffer (nullptr unless want_stage) which produce may fill and return.
+//   consume(o, m, result): result = pinned buffer holding the chunk's output.
+using ProduceFn = std::function<const void*(int64_t, int64_t, void*)>;
+using ConsumeFn = std::function<int(int64_t, int64_t, const void*)>;
+
+int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool want_stage, const ProduceFn& produce, const ConsumeFn& consume)
 {
     HIPCHK(c, hipSetDevice(c->device));
-    const int64_t step = std::min(c->chunk, n);
+    step = std::min(step > 0 ? std::min(step, c->chunk) : c->chunk, n);
     int rc = ensure_io(c, step);
     if (rc) return rc;
-    if (in_ptrs && c->pin_in_leaves < step) {
-        for (int i = 0; i < 2; ++i) {
-            if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
-            c->pin_in[i] = nullptr;
-        }
-        c->pin_in_leaves = 0;
-        for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc(&c->pin_in[i], (size_t)step * 2048, hipHostMallocDefault));
-        c->pin_in_leaves = step;
-    }
     const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
+    if (want_stage && (rc = ensure_stage(c, step))) return rc;
     int64_t prev_off = -1, prev_m = 0;
     int prev_slot = 0, i = 0;
     auto drain = [&]() -> int {
         if (prev_off < 0) return VQHIP_OK;
         HIPCHK(c, hipEventSynchronize(c->ev_out[prev_slot]));
-        if (out_ptrs) {
-            const float* src = static_cast<const float*>(c->pin_out[prev_slot]);
-            float* const* dst = out_ptrs + prev_off;
-            host_parallel_for(prev_m, [=](int64_t a, int64_t b) {
-                for (int64_t l = a; l < b; ++l) std::memcpy(dst[l], src + l * 512, 2048);
-            });
-        } else {
-            std::memcpy(static_cast<char*>(out) + (size_t)prev_off * out_b, c->pin_out[prev_slot], (size_t)prev_m * out_b);
-        }
+        const int64_t o = prev_off;
         prev_off = -1;
-        return VQHIP_OK;
+        return consume(o, prev_m, c->pin_out[prev_slot]);
+    };
+    auto abort_run = [&](int code) {  // leave no work in flight that still references caller memory
+        hipStreamSynchronize(c->s_in);
+        hipStreamSynchronize(c->stream);
+        hipStreamSynchronize(c->s_out);
+        return code;
     };
     for (int64_t o = 0; o < n; o += step, ++i) {
         const int64_t m = std::min(step, n - o);
         const int slot = i & 1;
         void* d_in = is_encode ? (void*)c->dev_leaves[slot] : (void*)c->dev_idx[slot];
         void* d_out = is_encode ? (void*)c->dev_idx[slot] : (void*)c->dev_leaves[slot];
-        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0));   // slot's previous input consumed
-        const void* src = static_cast<const char*>(in) + (size_t)o * in_b;
-        if (in_ptrs) {
-            if (i >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[slot]));  // the H2D that last read this pinned buffer is done
-            float* stage = static_cast<float*>(c->pin_in[slot]);
-            const float* const* lp = in_ptrs + o;
-            host_parallel_for(m, [=](int64_t a, int64_t b) {
-                for (int64_t l = a; l < b; ++l) std::memcpy(stage + l * 512, lp[l], 2048);
-            });
-            src = stage;
-        }
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0));  // slot's previous input consumed
+        if (want_stage && i >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[slot]));  // the H2D that last read this pinned buffer is done
+        const void* src = produce(o, m, want_stage ? c->pin_in[slot] : nullptr);
+        if (!src) return abort_run(c->err.empty() ? fail(c, VQHIP_ERR_INVALID, "input source failed") : VQHIP_ERR_INVALID);
         HIPCHK(c, hipMemcpyAsync(d_in, src, (size_t)m * in_b, hipMemcpyHostToDevice, c->s_in));
         HIPCHK(c, hipEventRecord(c->ev_in[slot], c->s_in));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[slot], 0));  // slot's previous output drained to pinned
         rc = is_encode ? encode_chunk(c, c->dev_leaves[slot], m, c->dev_idx[slot], c->stream)
                        : decode_chunk(c, c->dev_idx[slot], m, c->dev_leaves[slot], c->stream);
-        if (rc) return rc;
+        if (rc) return abort_run(rc);
         HIPCHK(c, hipEventRecord(c->ev_done[slot], c->stream));
-        if ((rc = drain())) return rc;  // chunk i-1 -> caller, overlapped with chunk i on the GPU
+        if ((rc = drain())) return abort_run(rc);  // chunk i-1 -> caller, overlapped with chunk i on the GPU
         HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_done[slot], 0));
         HIPCHK(c, hipMemcpyAsync(c->pin_out[slot], d_out, (size_t)m * out_b, hipMemcpyDeviceToHost, c->s_out));
         HIPCHK(c, hipEventRecord(c->ev_out[slot], c->s_out));
         prev_off = o, prev_m = m, prev_slot = slot;
     }
-    if ((rc = drain())) return rc;
+    if ((rc = drain())) return abort_run(rc);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VQHIP_OK;
 }
+
+// gather per-leaf buffers into a contiguous (pinned) block / scatter a block into per-leaf buffers
+void gather_leaves(float* stage, const float* const* lp, int64_t m)
+{
+    host_parallel_for(m, [=](int64_t a, int64_t b) {
+        for (int64_t l = a; l < b; ++l) std::memcpy(stage + l * 512, lp[l], 2048);
+    });
+}
+void scatter_leaves(float* const* dst, const float* src, int64_t m)
+{
+    host_parallel_for(m, [=](int64_t a, int64_t b) {
+        for (int64_t l = a; l < b; ++l) std::memcpy(dst[l], src + l * 512, 2048);
+    });
+}
+
+// contiguous blocks or leaf-pointer arrays (vqhip_encode / _decode / _encode_leaves / _decode_leaves)
+int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out, int64_t n, const float* const* in_ptrs = nullptr,
+                      float* const* out_ptrs = nullptr)
+{
+    const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
+    const bool stage_in = in_ptrs || (is_encode && n >= 4096);  // leaf blocks go through pinned staging (threads), not the pageable-copy path
+    return run_pipeline(
+        c, is_encode, n, 0, stage_in,
+        [=](int64_t o, int64_t m, void* stage) -> const void* {
+            const void* src = static_cast<const char*>(in) + (size_t)o * in_b;
+            if (!stage) return src;
+            if (in_ptrs) gather_leaves(static_cast<float*>(stage), in_ptrs + o, m);
+            else host_parallel_copy(stage, src, (size_t)m * in_b);
+            return stage;
+        },
+        [=](int64_t o, int64_t m, const void* res) -> int {
+            if (out_ptrs) scatter_leaves(out_ptrs + o, static_cast<const float*>(res), m);
+            else host_parallel_copy(static_cast<char*>(out) + (size_t)o * out_b, res, (size_t)m * out_b);
+            return VQHIP_OK;
+        });
+}
+
+// ---------------- .vqvdb v3 container (reference src/Utils/VQVDB_Reader.{hpp,cpp}) ----------------
+// file : "VQVDB" | u8 version=3 | u8 numGrids | u32 numEmbeddings | u8 latentDimCount
+// grid : u32 nameLength | name | f32 transform[16] | u16 latentShape[latentDimCount] | u32 totalBlocks
+//        totalBlocks x { i32 origin[3] | u8 indices[64] }   (76 B per leaf)
+constexpr size_t REC_BYTES = 76;
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct FileCloser {
+    FILE* f;
+    ~FileCloser()
+    {
+        if (f) std::fclose(f);
+    }
+};
+
+// One decoded-side batch travelling from the reader thread to the pipeline: indices de-framed from the records,
+// origins, and the leaf addresses the caller's allocator returned for them.
+struct StreamBatch {
+    std::vector<uint8_t> idx;
+    std::vector<int32_t> origins;
+    std::vector<float*> ptrs;
+    std::vector<unsigned char> raw;
+};
 
 }  // namespace
 
@@ -932,6 +1016,18 @@ int vqhip_set_chunk_leaves(vqhip_codec* c, int64_t chunk)
     return VQHIP_OK;
 }
 
+int vqhip_reserve(vqhip_codec* c, int64_t n)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (n < 1) return fail(c, VQHIP_ERR_INVALID, "reserve: n_leaves < 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t m = std::min(n, c->chunk);
+    int rc = ensure_workspace(c, m);
+    if (!rc) rc = ensure_io(c, m);
+    if (!rc) rc = ensure_stage(c, m);
+    return rc;
+}
+
 int vqhip_encode_device(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, void* stream)
 {
     if (!c) return VQHIP_ERR_INVALID;
@@ -986,6 +1082,219 @@ int vqhip_decode_leaves(vqhip_codec* c, const uint8_t* indices, int64_t n, float
     if (!c) return VQHIP_ERR_INVALID;
     if (!leaf_ptrs || !indices || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode_leaves: null pointer or n_leaves < 1");
     return run_host_pipeline(c, false, indices, nullptr, n, nullptr, leaf_ptrs);
+}
+
+// ---- .vqvdb stream entry points: file read || GPU decode || leaf insert ----
+// Replaces the body of VQVAECodec::decompress (VQVAECodec.cpp:137-208): per grid, a reader thread reads and de-frames
+// batch k+1..k+2 and asks the caller's allocator for their leaf buffers while the GPU decodes batch k and the calling
+// thread scatters batch k-1 straight from pinned memory into those buffers.
+int vqhip_decompress_file(vqhip_codec* c, const char* path, int64_t batch_leaves, vqhip_grid_begin_fn grid_begin, vqhip_leaf_alloc_fn leaf_alloc,
+                          void* user, vqhip_stream_stats* stats)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!path || !leaf_alloc) return fail(c, VQHIP_ERR_INVALID, "decompress_file: null path or leaf allocator");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(c, VQHIP_ERR_INVALID, std::string("Cannot open input file: ") + path);
+    FileCloser closer{f};
+    const double t_start = now_s();
+    vqhip_stream_stats st;
+    std::memset(&st, 0, sizeof st);
+    unsigned char h[12];
+    if (std::fread(h, 1, 12, f) != 12) return fail(c, VQHIP_ERR_INVALID, "Failed to read file header.");
+    if (std::memcmp(h, "VQVDB", 5) != 0) return fail(c, VQHIP_ERR_INVALID, "Invalid file magic; not a .vqvdb file.");
+    if (h[5] != 3) return fail(c, VQHIP_ERR_INVALID, "Unsupported .vqvdb version " + std::to_string((int)h[5]) + " (expected 3).");
+    const int n_grids = h[6], dim_count = h[11];
+    uint32_t num_emb;
+    std::memcpy(&num_emb, h + 7, 4);
+    if (dim_count != 3) return fail(c, VQHIP_ERR_INVALID, "latent rank " + std::to_string(dim_count) + " in file; this codec decodes [4,4,4] latents");
+
+    for (int g = 0; g < n_grids; ++g) {
+        vqhip_grid_info gi;
+        std::memset(&gi, 0, sizeof gi);
+        uint32_t name_len = 0, total = 0;
+        uint16_t shp[3];
+        std::string name;
+        if (std::fread(&name_len, 4, 1, f) != 1 || name_len > (1u << 20)) return fail(c, VQHIP_ERR_INVALID, "Failed to read grid name length.");
+        name.resize(name_len);
+        if (name_len && std::fread(&name[0], 1, name_len, f) != name_len) return fail(c, VQHIP_ERR_INVALID, "Failed to read grid name.");
+        if (std::fread(gi.transform, 4, 16, f) != 16) return fail(c, VQHIP_ERR_INVALID, "Failed to read transform.");
+        if (std::fread(shp, 2, 3, f) != 3) return fail(c, VQHIP_ERR_INVALID, "Failed to read latent shape.");
+        if (std::fread(&total, 4, 1, f) != 1) return fail(c, VQHIP_ERR_INVALID, "File appears truncated, failed to read total block count.");
+        if (shp[0] != 4 || shp[1] != 4 || shp[2] != 4)
+            return fail(c, VQHIP_ERR_INVALID, "grid '" + name + "' has latent shape [" + std::to_string(shp[0]) + "," + std::to_string(shp[1]) + "," +
+                                                  std::to_string(shp[2]) + "]; this codec decodes [4,4,4]");
+        gi.name = name.c_str();
+        gi.grid_index = g;
+        for (int i = 0; i < 3; ++i) gi.latent_shape[i] = shp[i];
+        gi.num_embeddings = num_emb;
+        gi.total_blocks = total;
+        if (grid_begin && grid_begin(user, &gi) != 0) return fail(c, VQHIP_ERR_INVALID, "grid_begin callback failed for grid '" + name + "'");
+        ++st.grids;
+        const int64_t n = total;
+        if (n == 0) continue;
+        const int64_t step = std::min(batch_leaves > 0 ? std::min(batch_leaves, c->chunk) : c->chunk, n);
+        const int64_t nb = (n + step - 1) / step;
+
+        constexpr int Q = 3;
+        StreamBatch slot[Q];
+        std::mutex mu;
+        std::condition_variable cv;
+        int64_t produced = 0, consumed = 0;
+        bool failed = false, stop = false;
+        std::string herr;
+        double read_s = 0, alloc_s = 0, wait_s = 0, copy_s = 0;
+        std::thread reader([&] {
+            auto bail = [&](const std::string& m) {
+                std::lock_guard<std::mutex> lk(mu);
+                herr = m;
+                failed = true;
+                cv.notify_all();
+            };
+            for (int64_t k = 0; k < nb; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || k - consumed < Q; });
+                    if (stop) return;
+                }
+                const int64_t m = std::min(step, n - k * step);
+                StreamBatch& B = slot[k % Q];
+                double t = now_s();
+                B.raw.resize((size_t)m * REC_BYTES);
+                if (std::fread(B.raw.data(), REC_BYTES, (size_t)m, f) != (size_t)m) return bail("File truncated: incomplete block data.");
+                B.idx.resize((size_t)m * 64);
+                B.origins.resize((size_t)m * 3);
+                B.ptrs.assign((size_t)m, nullptr);
+                const unsigned char* p = B.raw.data();
+                for (int64_t l = 0; l < m; ++l, p += REC_BYTES) {
+                    std::memcpy(&B.origins[3 * l], p, 12);
+                    std::memcpy(&B.idx[64 * l], p + 12, 64);
+                }
+                read_s += now_s() - t;
+                t = now_s();
+                const int rc = leaf_alloc(user, g, B.origins.data(), m, B.ptrs.data());
+                alloc_s += now_s() - t;
+                if (rc != 0) return bail("leaf_alloc callback failed (" + std::to_string(rc) + ")");
+                for (int64_t l = 0; l < m; ++l)
+                    if (!B.ptrs[l]) return bail("leaf_alloc callback left a null leaf pointer");
+                std::lock_guard<std::mutex> lk(mu);
+                produced = k + 1;
+                cv.notify_all();
+            }
+        });
+        const int rc = run_pipeline(
+            c, false, n, step, false,
+            [&](int64_t o, int64_t, void*) -> const void* {
+                const int64_t k = o / step;
+                const double t = now_s();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || produced > k; });
+                wait_s += now_s() - t;
+                if (produced <= k) {
+                    c->err = herr;
+                    return nullptr;
+                }
+                return slot[k % Q].idx.data();
+            },
+            [&](int64_t o, int64_t m, const void* res) -> int {
+                const int64_t k = o / step;
+                const double t = now_s();
+                scatter_leaves(slot[k % Q].ptrs.data(), static_cast<const float*>(res), m);
+                copy_s += now_s() - t;
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = k + 1;
+                cv.notify_all();
+                return VQHIP_OK;
+            });
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        reader.join();
+        if (rc) return rc;
+        st.leaves += n;
+        st.read_s += read_s, st.alloc_s += alloc_s, st.io_wait_s += wait_s, st.copy_s += copy_s;
+    }
+    st.wall_s = now_s() - t_start;
+    if (stats) *stats = st;
+    return VQHIP_OK;
+}
+
+// Replaces the body of VQVAECodec::compress (VQVAECodec.cpp:78-134): gather the leaf buffers into pinned memory,
+// encode on the GPU, frame {origin, 64 indices} records and append them to the file while the next batch encodes.
+int vqhip_compress_file(vqhip_codec* c, const char* path, const vqhip_grid_source* grids, int n_grids, int64_t batch_leaves, vqhip_stream_stats* stats)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!path || !grids) return fail(c, VQHIP_ERR_INVALID, "compress_file: null path or grid list");
+    if (n_grids < 1 || n_grids > 255) return fail(c, VQHIP_ERR_INVALID, "compress_file: a .vqvdb file holds 1..255 grids");
+    for (int g = 0; g < n_grids; ++g) {
+        const vqhip_grid_source& G = grids[g];
+        if (!G.name || G.n_leaves < 0 || G.n_leaves > 0xFFFFFFFFll || (G.n_leaves > 0 && (!G.leaf_ptrs || !G.origins)))
+            return fail(c, VQHIP_ERR_INVALID, "compress_file: grid " + std::to_string(g) + " has no name, no leaves/origins or more than 2^32-1 leaves");
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(c, VQHIP_ERR_INVALID, std::string("Cannot open output file: ") + path);
+    FileCloser closer{f};
+    const double t_start = now_s();
+    vqhip_stream_stats st;
+    std::memset(&st, 0, sizeof st);
+    bool wfail = false;
+    auto put = [&](const void* p, size_t n) {
+        if (n && std::fwrite(p, 1, n, f) != n) wfail = true;
+    };
+    unsigned char h[12];
+    std::memcpy(h, "VQVDB", 5);
+    h[5] = 3;
+    h[6] = (unsigned char)n_grids;
+    const uint32_t num_emb = 256;
+    std::memcpy(h + 7, &num_emb, 4);
+    h[11] = 3;
+    put(h, 12);
+    std::vector<unsigned char> rec;
+    for (int g = 0; g < n_grids; ++g) {
+        const vqhip_grid_source& G = grids[g];
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        const uint32_t name_len = (uint32_t)std::strlen(G.name), total = (uint32_t)G.n_leaves;
+        const uint16_t shp[3] = {4, 4, 4};
+        put(&name_len, 4);
+        put(G.name, name_len);
+        put(G.transform ? G.transform : ident, 64);
+        put(shp, 6);
+        put(&total, 4);
+        ++st.grids;
+        if (wfail) return fail(c, VQHIP_ERR_INVALID, "Failed to write to .vqvdb file.");
+        if (G.n_leaves == 0) continue;
+        double copy_s = 0, write_s = 0;
+        const int rc = run_pipeline(
+            c, true, G.n_leaves, batch_leaves, true,
+            [&](int64_t o, int64_t m, void* stage) -> const void* {
+                const double t = now_s();
+                gather_leaves(static_cast<float*>(stage), G.leaf_ptrs + o, m);
+                copy_s += now_s() - t;
+                return stage;
+            },
+            [&](int64_t o, int64_t m, const void* res) -> int {
+                const double t = now_s();
+                rec.resize((size_t)m * REC_BYTES);
+                const uint8_t* idx = static_cast<const uint8_t*>(res);
+                unsigned char* p = rec.data();
+                for (int64_t l = 0; l < m; ++l, p += REC_BYTES) {
+                    std::memcpy(p, G.origins + 3 * (o + l), 12);
+                    std::memcpy(p + 12, idx + 64 * l, 64);
+                }
+                put(rec.data(), rec.size());
+                write_s += now_s() - t;
+                return wfail ? fail(c, VQHIP_ERR_INVALID, "Failed to write to .vqvdb file.") : VQHIP_OK;
+            });
+        if (rc) return rc;
+        st.leaves += G.n_leaves;
+        st.copy_s += copy_s, st.read_s += write_s;
+    }
+    closer.f = nullptr;
+    if (std::fclose(f) != 0) return fail(c, VQHIP_ERR_INVALID, "Error closing the output file.");
+    st.wall_s = now_s() - t_start;
+    if (stats) *stats = st;
+    return VQHIP_OK;
 }
 
 // ---- in-process multi-GPU front end: one codec + one host thread per device, contiguous leaf ranges ----

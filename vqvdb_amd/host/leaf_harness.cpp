@@ -6,6 +6,8 @@
 //
 //   leaf_harness compress   <pack> <leaves.f32> <out.vqvdb> <batch>
 //   leaf_harness decompress <pack> <in.vqvdb>   <out.f32>   <batch>
+//   leaf_harness compress_stream   <pack> <leaves.f32> <out.vqvdb> <batch>   (vqhip_compress_file: overlapped pipeline)
+//   leaf_harness decompress_stream <pack> <in.vqvdb>   <out.f32>   <batch>   (vqhip_decompress_file)
 //   leaf_harness errors     <pack>
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
 //   leaf_harness makefile   <out.vqvdb> <n_leaves> (synthetic indices; config-3 input)
@@ -14,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <unordered_map>
 
 #include "../../include/vqvdb_hip_backend.hpp"
 #include "vqvdb_stream.hpp"
@@ -110,6 +113,97 @@ int decompress(const std::string& pack, const std::string& in, const std::string
 	}
 	const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
 	std::printf("Multi-Grid Decompression Complete in %lld ms (%zu leaves, batch %zu).\n", static_cast<long long>(ms), leafNo, batch);
+	return 0;
+}
+
+// ---- whole-file entry points of the C ABI (read || decode || leaf insert overlapped inside the library) ----
+struct CodecHandle {
+	vqhip_codec* h = nullptr;
+	explicit CodecHandle(const std::string& pack) {
+		if (vqhip_create(pack.c_str(), nullptr, 0, 0, &h) != VQHIP_OK) throw std::runtime_error(vqhip_last_error(nullptr));
+	}
+	void reserve(size_t batch) {  // one-time allocations out of the timed call, like model loading in create()
+		if (vqhip_reserve(h, static_cast<int64_t>(batch)) != VQHIP_OK) throw std::runtime_error(vqhip_last_error(h));
+	}
+	~CodecHandle() { vqhip_destroy(h); }
+};
+
+void printStats(const char* what, const vqhip_stream_stats& st, size_t batch) {
+	std::printf("%s: %lld leaves in %d grid(s), %.1f ms wall = %.3f M leaves/s (batch %zu; file+framing %.1f ms, leaf alloc %.1f ms, "
+	            "gather/scatter %.1f ms, pipeline waited for reader %.1f ms)\n",
+	            what, static_cast<long long>(st.leaves), st.grids, st.wall_s * 1e3, st.leaves / st.wall_s / 1e6, batch, st.read_s * 1e3,
+	            st.alloc_s * 1e3, st.copy_s * 1e3, st.io_wait_s * 1e3);
+}
+
+int compressStream(const std::string& pack, const std::string& in, const std::string& out, size_t batch) {
+	CodecHandle codec(pack);
+	codec.reserve(batch);
+	const std::vector<float> all = readFloats(in);
+	const size_t total = all.size() / LEAF_VOXELS;
+	std::vector<const float*> ptrs(total);
+	std::vector<int32_t> origins(total * 3);
+	for (size_t i = 0; i < total; ++i) {
+		ptrs[i] = all.data() + i * LEAF_VOXELS;  // stand-in for leaf.buffer().data()
+		const vqvdb::Coord3i o = originOf(i);
+		origins[3 * i] = o.x, origins[3 * i + 1] = o.y, origins[3 * i + 2] = o.z;
+	}
+	vqhip_grid_source g{};
+	g.name = "density";
+	g.transform = nullptr;
+	g.leaf_ptrs = ptrs.data();
+	g.origins = origins.data();
+	g.n_leaves = static_cast<int64_t>(total);
+	vqhip_stream_stats st;
+	if (vqhip_compress_file(codec.h, out.c_str(), &g, 1, static_cast<int64_t>(batch), &st) != VQHIP_OK) throw std::runtime_error(vqhip_last_error(codec.h));
+	printStats("compress_stream", st, batch);
+	return 0;
+}
+
+// Leaf store standing in for an OpenVDB tree: touchLeaf = hash-map insert keyed by origin + a 2 KiB leaf buffer.
+struct LeafStore {
+	struct Key {
+		int32_t x, y, z;
+		bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; }
+	};
+	struct Hash {
+		size_t operator()(const Key& k) const { return (static_cast<size_t>(static_cast<uint32_t>(k.x)) * 73856093u) ^ (static_cast<size_t>(static_cast<uint32_t>(k.y)) * 19349663u) ^ (static_cast<size_t>(static_cast<uint32_t>(k.z)) * 83492791u); }
+	};
+	std::unordered_map<Key, float*, Hash> leaves;
+	std::vector<float*> order;  // file order, for the output file
+	std::vector<std::unique_ptr<float[]>> slabs;
+	static int beginGrid(void* user, const vqhip_grid_info* g) {  // openvdb::FloatGrid::create + setName/setTransform in the real caller
+		LeafStore& self = *static_cast<LeafStore*>(user);
+		self.leaves.reserve(self.leaves.size() + g->total_blocks);
+		self.order.reserve(self.order.size() + g->total_blocks);
+		return 0;
+	}
+	static int alloc(void* user, int, const int32_t* origins, int64_t n, float** out) {
+		LeafStore& self = *static_cast<LeafStore*>(user);
+		self.slabs.emplace_back(new float[static_cast<size_t>(n) * LEAF_VOXELS]);
+		float* base = self.slabs.back().get();
+		for (int64_t i = 0; i < n; ++i) {
+			float* leaf = base + i * LEAF_VOXELS;
+			self.leaves[Key{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]}] = leaf;
+			self.order.push_back(leaf);
+			out[i] = leaf;
+		}
+		return 0;
+	}
+};
+
+int decompressStream(const std::string& pack, const std::string& in, const std::string& out, size_t batch) {
+	CodecHandle codec(pack);
+	codec.reserve(batch);
+	LeafStore store;
+	vqhip_stream_stats st;
+	if (vqhip_decompress_file(codec.h, in.c_str(), static_cast<int64_t>(batch), &LeafStore::beginGrid, &LeafStore::alloc, &store, &st) != VQHIP_OK)
+		throw std::runtime_error(vqhip_last_error(codec.h));
+	printStats("decompress_stream", st, batch);
+	if (store.leaves.size() != store.order.size()) throw std::runtime_error("duplicate origins in stream");
+	if (out != "/dev/null") {
+		std::ofstream of(out, std::ios::binary | std::ios::trunc);
+		for (const float* leaf : store.order) of.write(reinterpret_cast<const char*>(leaf), LEAF_VOXELS * sizeof(float));
+	}
 	return 0;
 }
 
@@ -215,6 +309,8 @@ int main(int argc, char** argv) {
 		const std::string mode = argc > 1 ? argv[1] : "";
 		if (mode == "compress" && argc == 6) return compress(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "decompress" && argc == 6) return decompress(argv[2], argv[3], argv[4], std::stoul(argv[5]));
+		if (mode == "compress_stream" && argc == 6) return compressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
+		if (mode == "decompress_stream" && argc == 6) return decompressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "errors" && argc == 3) return errors(argv[2]);
 		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
 		if (mode == "makefile" && argc == 4) return makefile(argv[2], std::stoul(argv[3]));
