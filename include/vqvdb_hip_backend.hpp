@@ -52,6 +52,10 @@ class HipBackend final : public IVQVAECodec {
 
 	const std::vector<int64_t>& getLatentShape() const override { return latentShape_; }
 
+	// Extension: the C handle, for callers that use the leaf-pointer or whole-file entry points of vqvdb_hip.h
+	// (vqhip_encode_leaves, vqhip_decompress_file, vqhip_reserve ...) next to the IVQVAECodec interface.
+	vqhip_codec* handle() const { return codec_; }
+
    private:
 	explicit HipBackend(const CodecConfig& config) {
 		if (config.device != CodecConfig::Device::CUDA)
