@@ -145,6 +145,33 @@ int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
  * cook, the way the reference backends pay model loading in IVQVAECodec::create. */
 int vqhip_reserve(vqhip_codec* codec, int64_t n_leaves);
 
+/* ---- codebook training (extension; SURVEY.md §8 f-2, stage 1) ----------------------------------------------
+ * The training-mode forward of VectorQuantizerEMA (python/VQVAE_v2.py:107-156) on the encoder's outputs: assign
+ * with the reference's expanded distance against the LIVE codebook, accumulate encodings_sum / dw / the
+ * commitment error, EMA-update cluster_size / embed_avg / embedding.  Data parallel: every rank computes the
+ * statistics of its own leaves into one flat buffer, the host all-reduces that buffer (RCCL over xGMI:
+ * torch.distributed, vqvdb_amd/codebook_training.py), then every rank applies the identical update — the only
+ * collective on the path.  The encoder / decoder weights are not trained here.
+ * stats layout (VQHIP_VQ_STATS_FLOATS floats, device memory):
+ *   [0,256) encodings_sum | [256, 256+32768) dw[256][128] | [33024, 33280) sum over a code's rows of |z-e|^2 | [33280] rows */
+#define VQHIP_VQ_STATS_FLOATS (256 + 256 * 128 + 256 + 1)
+/* Start (or restart) training state: cluster_size[256] (NULL = ones) and embed_avg[256][128] (NULL = a copy of the
+ * embedding), i.e. the reference's initial buffers (VQVAE_v2.py:103-105) or a checkpoint's. */
+int vqhip_train_begin(vqhip_codec* codec, const float* cluster_size, const float* embed_avg);
+/* Encoder forward + latent + assignment + local statistics for one batch (n_leaves <= chunk size) resident in HBM.
+ * indices_dev ([n][64] uint8) and latent_dev ([n*64][128] float, the reference's `flat` rows) may be NULL. */
+int vqhip_train_vq_stats_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, float* stats_dev, uint8_t* indices_dev,
+                                float* latent_dev, void* hip_stream);
+/* EMA update from the (all-reduced) statistics: cluster_size = decay*cluster_size + (1-decay)*encodings_sum, embed_avg likewise
+ * with dw, embedding = embed_avg / max(cluster_size, eps)  (VQVAE_v2.py:135-144; reference defaults decay 0.95, eps 1e-4). */
+int vqhip_train_vq_update_device(vqhip_codec* codec, const float* stats_dev, float decay, float eps, void* hip_stream);
+/* Host copies of the live state (any pointer may be NULL): checkpointing, dead-code reset (VQVAE_v2.py:382-417). */
+int vqhip_train_get_state(vqhip_codec* codec, float* embedding, float* cluster_size, float* embed_avg);
+int vqhip_train_set_state(vqhip_codec* codec, const float* embedding, const float* cluster_size, const float* embed_avg);
+/* Rebuild the inference tables that derive from the codebook (folded VQ search, decoder stem table).  The inference
+ * entry points do this on demand; calling it explicitly keeps the cost out of the first encode/decode. */
+int vqhip_train_commit(vqhip_codec* codec);
+
 /* ---- measurement hooks (bench.py / tests) ---- */
 
 /* Per-kernel timing with HIP events on the launch stream.  While enabled, every kernel

@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libvqvae_oracle.so")
 ENC_DEBUG = ["e_y1", "e_a1", "e_y4", "e_a6", "e_x7", "e_y9", "e_x11", "e_x12", "e_z"]
 DEC_DEBUG = ["d_ystem", "d_d2", "d_y4", "d_x6", "d_x7", "d_up", "d_ps", "d_pre"]
 DEBUG_SLOTS = ENC_DEBUG + DEC_DEBUG
+VQ_STATS_FLOATS = 256 + 256 * 128 + 256 + 1   # counts | dw | per-code squared error | rows
 DEBUG_SHAPES = {
     "e_y1": (16, 512), "e_a1": (16, 512), "e_y4": (16, 512), "e_a6": (16, 512), "e_x7": (32, 64),
     "e_y9": (32, 64), "e_x11": (32, 64), "e_x12": (32, 64), "e_z": (128, 64),
@@ -53,6 +54,10 @@ class Oracle:
                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         self.lib.vqo_expf.restype = ctypes.c_float
         self.lib.vqo_expf.argtypes = [ctypes.c_float]
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        self.lib.vqo_vq_assign.argtypes = [vp, i64, vp, vp, ctypes.c_int]
+        self.lib.vqo_vq_stats.argtypes = [vp, vp, i64, vp, vp]
+        self.lib.vqo_vq_update.argtypes = [vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
 
     def _dbg(self, B, want):
         if not want:
@@ -91,3 +96,32 @@ class Oracle:
 
     def expf(self, x: float) -> float:
         return float(self.lib.vqo_expf(ctypes.c_float(x)))
+
+    # ---- codebook training: VectorQuantizerEMA.forward in training mode (VQVAE_v2.py:107-156) ----
+    def latent(self, leaves: np.ndarray, threads: int = 1) -> np.ndarray:
+        """Encoder output as the reference's `flat` rows: [n*64, 128], row = leaf*64 + position (:113-114)."""
+        _, dbg = self.encode(leaves, threads=threads, debug=["e_z"])
+        return np.ascontiguousarray(dbg["e_z"].transpose(0, 2, 1)).reshape(-1, 128)
+
+    def vq_assign(self, z: np.ndarray, embedding: np.ndarray, threads: int = 1) -> np.ndarray:
+        z = np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 128)
+        E = np.ascontiguousarray(embedding, dtype=np.float32).reshape(256, 128)
+        idx = np.zeros(z.shape[0], dtype=np.uint8)
+        assert self.lib.vqo_vq_assign(z.ctypes.data, z.shape[0], E.ctypes.data, idx.ctypes.data, threads) == 0
+        return idx
+
+    def vq_stats(self, z: np.ndarray, idx: np.ndarray, embedding: np.ndarray) -> np.ndarray:
+        z = np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 128)
+        idx = np.ascontiguousarray(idx, dtype=np.uint8).reshape(-1)
+        E = np.ascontiguousarray(embedding, dtype=np.float32).reshape(256, 128)
+        stats = np.zeros(VQ_STATS_FLOATS, dtype=np.float32)
+        assert self.lib.vqo_vq_stats(z.ctypes.data, idx.ctypes.data, z.shape[0], E.ctypes.data, stats.ctypes.data) == 0
+        return stats
+
+    def vq_update(self, stats: np.ndarray, state: dict, decay: float = 0.95, eps: float = 1e-4) -> dict:
+        """state = {embedding, cluster_size, embed_avg}; returns the updated copy."""
+        new = {k: np.ascontiguousarray(v, dtype=np.float32).copy() for k, v in state.items()}
+        stats = np.ascontiguousarray(stats, dtype=np.float32)
+        assert self.lib.vqo_vq_update(stats.ctypes.data, decay, eps, new["cluster_size"].ctypes.data, new["embed_avg"].ctypes.data,
+                                      new["embedding"].ctypes.data) == 0
+        return new

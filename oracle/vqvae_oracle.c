@@ -755,3 +755,102 @@ int vqo_decode_ex(const float* const* W, const uint8_t* idx, int64_t B, float* o
     tail_free(tail);
     return err;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Codebook training: the training-mode forward of VectorQuantizerEMA on latent rows
+ * (python/VQVAE_v2.py:107-156).  TEST INFRASTRUCTURE like the rest of this file; the GPU kernels
+ * (vqvdb_amd/csrc/vq_train_kernels.h) follow the same operation order:
+ *   assign : dist_k = (zz + ee_k) - 2 * dot_k as in the "faithful" encode path above
+ *            (zz = chain over channels with (c&4)==0 + chain over the others, dot in "P8" order), first minimum
+ *   stats  : rows split into 16 equal contiguous segments; per (code, segment, channel) an ascending fp32
+ *            chain of the member rows; segments added ascending in fp32 from 0 -> dw (= encodings^T @ flat, :137);
+ *            counts = encodings.sum(0) (:134); sq[k]: per (segment, channel pair 2l,2l+1) fp32 fmaf chain of
+ *            (z-e)^2 over member rows, summed in fp64 (segment asc, pair asc) -> float
+ *   update : cluster_size = fmaf(alpha, counts, cluster_size*decay), embed_avg likewise, alpha = (float)(1-(double)decay),
+ *            embedding = embed_avg / max(cluster_size, eps)                                          (:135-144)
+ * stats layout: [0,256) counts | [256,256+32768) dw | [33024,33280) sq | [33280] rows
+ * ------------------------------------------------------------------------------------------------ */
+#define VQ_ST_DW 256
+#define VQ_ST_SQ (256 + 256 * 128)
+#define VQ_ST_ROWS (256 + 256 * 128 + 256)
+
+int vqo_vq_assign(const float* z, int64_t n_rows, const float* E, uint8_t* idx, int nthreads)
+{
+    float ee[256];
+    int p8_128[128];
+    vqo_code_norms(E, ee);
+    korder_p8(128, p8_128);
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const float* v = z + r * 128;
+        float zz0 = 0.0f, zz1 = 0.0f;
+        for (int c = 0; c < 128; ++c) {
+            if ((c & 4) == 0) zz0 = fmaf(v[c], v[c], zz0);
+            else zz1 = fmaf(v[c], v[c], zz1);
+        }
+        const float zz = zz0 + zz1;
+        float best = INFINITY;
+        int bi = 0;
+        for (int k = 0; k < 256; ++k) {
+            float dot = 0.0f;
+            for (int cc = 0; cc < 128; ++cc) dot = fmaf(E[k * 128 + p8_128[cc]], v[p8_128[cc]], dot);
+            const float d = (zz + ee[k]) - 2.0f * dot;
+            if (d < best) { best = d; bi = k; }
+        }
+        idx[r] = (uint8_t)bi;
+    }
+    return 0;
+}
+
+int vqo_vq_stats(const float* z, const uint8_t* idx, int64_t n_rows, const float* E, float* stats)
+{
+    if (n_rows % 16 != 0) return 1;
+    const int64_t seg = n_rows / 16;
+    for (int k = 0; k < 256; ++k) {
+        float part[16][128], sqp[16][64];
+        int cnt = 0;
+        for (int w = 0; w < 16; ++w) {
+            for (int c = 0; c < 128; ++c) part[w][c] = 0.0f;
+            for (int l = 0; l < 64; ++l) sqp[w][l] = 0.0f;
+            for (int64_t r = w * seg; r < (w + 1) * seg; ++r) {
+                if (idx[r] != k) continue;
+                ++cnt;
+                const float* v = z + r * 128;
+                for (int c = 0; c < 128; ++c) part[w][c] = part[w][c] + v[c];
+                for (int l = 0; l < 64; ++l) {
+                    const float d0 = v[2 * l] - E[k * 128 + 2 * l], d1 = v[2 * l + 1] - E[k * 128 + 2 * l + 1];
+                    sqp[w][l] = fmaf(d0, d0, sqp[w][l]);
+                    sqp[w][l] = fmaf(d1, d1, sqp[w][l]);
+                }
+            }
+        }
+        for (int c = 0; c < 128; ++c) {
+            float s = 0.0f;
+            for (int w = 0; w < 16; ++w) s = s + part[w][c];
+            stats[VQ_ST_DW + k * 128 + c] = s;
+        }
+        double sq = 0.0;
+        for (int w = 0; w < 16; ++w)
+            for (int l = 0; l < 64; ++l) sq += (double)sqp[w][l];
+        stats[VQ_ST_SQ + k] = (float)sq;
+        stats[k] = (float)cnt;
+    }
+    stats[VQ_ST_ROWS] = (float)n_rows;
+    return 0;
+}
+
+int vqo_vq_update(const float* stats, float decay, float eps, float* cluster_size, float* embed_avg, float* E)
+{
+    const float alpha = (float)(1.0 - (double)decay);
+    for (int k = 0; k < 256; ++k) {
+        const float cs = fmaf(alpha, stats[k], cluster_size[k] * decay);
+        for (int c = 0; c < 128; ++c) {
+            const float avg = fmaf(alpha, stats[VQ_ST_DW + k * 128 + c], embed_avg[k * 128 + c] * decay);
+            embed_avg[k * 128 + c] = avg;
+            E[k * 128 + c] = avg / (cs < eps ? eps : cs);
+        }
+        cluster_size[k] = cs;
+    }
+    return 0;
+}

@@ -1,0 +1,117 @@
+"""GPU tests of the codebook-training entry points (vqhip_train_*, run with -m gpu on an MI355X):
+HIP kernels vs the oracle's training restatement (bit-exact: same operation order) and vs golden vectors of the
+imported reference quantizer in training mode (1e-5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import Oracle, VQ_STATS_FLOATS
+from test_codebook_training import gt, run_reference_schedule  # noqa: F401  (fixture + shared schedule)
+from vqvdb_amd import synth, weightpack
+from vqvdb_amd.codebook_training import CodebookTrainer, K, metrics_from_stats
+from vqvdb_amd.codec import HipCodec
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.where(a == 0, 0.0, a).astype(np.float32).view(np.uint32)
+
+
+@pytest.fixture()
+def tcodec(weights):
+    c = HipCodec(weightpack.dumps(weights))
+    c.train_begin()
+    yield c
+    c.close()
+
+
+def _gpu_stats(codec, leaves):
+    n = len(leaves)
+    x = torch.from_numpy(leaves).cuda()
+    stats = torch.zeros(VQ_STATS_FLOATS, device="cuda")
+    idx = torch.zeros((n, 64), dtype=torch.uint8, device="cuda")
+    z = torch.zeros((n * 64, 128), device="cuda")
+    codec.train_vq_stats_device(x.data_ptr(), n, stats.data_ptr(), idx.data_ptr(), z.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return stats, idx.cpu().numpy().reshape(-1), z.cpu().numpy()
+
+
+def test_training_step_bit_exact_vs_oracle(tcodec, oracle, weights):
+    state = {"embedding": weights["quantizer.embedding"].copy(), "cluster_size": np.ones(K, np.float32),
+             "embed_avg": weights["quantizer.embedding"].copy()}
+    for step, n in enumerate((200, 33, 1)):                      # ragged tiles; steps 1, 2 run against the LIVE codebook
+        leaves = synth.make_leaves(n, seed=31 + step)
+        stats, idx, z = _gpu_stats(tcodec, leaves)
+        oz = oracle.latent(leaves, threads=8)
+        assert np.array_equal(_bits(z), _bits(oz)), step
+        oidx = oracle.vq_assign(oz, state["embedding"], threads=8)
+        assert np.array_equal(idx, oidx), step
+        ostats = oracle.vq_stats(oz, oidx, state["embedding"])
+        assert np.array_equal(_bits(stats.cpu().numpy()), _bits(ostats)), step
+        tcodec.train_vq_update_device(stats.data_ptr(), 0.95, 1e-4, torch.cuda.current_stream().cuda_stream)
+        state = oracle.vq_update(ostats, state, 0.95, 1e-4)
+        got = tcodec.train_get_state()
+        for k in state:
+            assert np.array_equal(_bits(got[k]), _bits(state[k])), (step, k)
+
+
+def test_training_matches_reference_golden(tcodec, weights, gt):  # noqa: F811
+    keep = {}
+
+    def latent(leaves, st):
+        keep["stats"], keep["idx"], z = _gpu_stats(tcodec, leaves)
+        return z
+
+    def update(stats, st):
+        tcodec.train_vq_update_device(keep["stats"].data_ptr(), 0.95, 1e-4, torch.cuda.current_stream().cuda_stream)
+        return tcodec.train_get_state()
+
+    run_reference_schedule(gt, latent, lambda z, st: keep["idx"], lambda z, idx, st: keep["stats"].cpu().numpy(), update, weights)
+
+
+def test_commit_refreshes_inference_tables(tcodec, weights):
+    """After training the inference entry points follow the live codebook: same results as a fresh codec / the oracle
+    built from the updated embedding."""
+    tr = CodebookTrainer(tcodec)
+    for s in range(3):
+        m = tr.step(torch.from_numpy(synth.make_leaves(256, seed=60 + s)).cuda(), keep_latent=(s == 2))
+        assert m["rows"] == 256 * 64 and 0 < m["vq_loss"] < 1 and 1 <= m["perplexity"] <= 256
+    sd = tr.state_dict()
+    assert set(sd) == {"quantizer.embedding", "quantizer.cluster_size", "quantizer.embed_avg"}
+    assert not np.array_equal(sd["quantizer.embedding"], weights["quantizer.embedding"])
+    w2 = dict(weights)
+    w2["quantizer.embedding"] = sd["quantizer.embedding"]
+    o2 = Oracle(w2, [t[0] for t in synth.TENSORS])
+    leaves = synth.make_leaves(300, seed=70)
+    idx = tcodec.encode(leaves)                                  # refreshes the folded tables on demand
+    assert np.array_equal(idx, o2.encode(leaves, threads=8))
+    assert np.array_equal(_bits(tcodec.decode(idx)), _bits(o2.decode(idx, threads=8)))
+    fresh = HipCodec(weightpack.dumps(w2))
+    assert np.array_equal(fresh.encode(leaves), idx)
+    fresh.close()
+    # dead-code reset through the trainer: dead codes get rows of the kept latent, live state stays consistent
+    n_dead = tr.reset_dead_codes(generator=torch.Generator(device="cuda").manual_seed(1))
+    st = tcodec.train_get_state()
+    assert n_dead == int((sd["quantizer.cluster_size"] < 1.0).sum()) and (st["cluster_size"] >= 1.0).all()
+    tr.finish()
+    assert np.array_equal(tcodec.encode(leaves[:10]), Oracle({**w2, "quantizer.embedding": st["embedding"]}, [t[0] for t in synth.TENSORS]).encode(leaves[:10]))
+
+
+def test_training_entry_points_fail_loudly(weights):
+    c = HipCodec(weightpack.dumps(weights))
+    x = torch.zeros((4, 512), device="cuda")
+    stats = torch.zeros(VQ_STATS_FLOATS, device="cuda")
+    with pytest.raises(RuntimeError, match="vqhip_train_begin"):
+        c.train_vq_stats_device(x.data_ptr(), 4, stats.data_ptr())
+    c.train_begin()
+    with pytest.raises(RuntimeError, match="null pointer"):
+        c.train_vq_stats_device(0, 4, stats.data_ptr())
+    c.set_chunk_leaves(32)
+    with pytest.raises(RuntimeError, match="chunk size"):
+        c.train_vq_stats_device(x.data_ptr(), 64, stats.data_ptr())
+    with pytest.raises(RuntimeError, match="decay"):
+        c.train_vq_update_device(stats.data_ptr(), 1.5, 1e-4)
+    c.close()

@@ -89,6 +89,8 @@ ABI_SYMBOLS = [
     "vqhip_profile_read", "vqhip_debug_enable", "vqhip_debug_fetch", "vqhip_selftest_mfma", "vqhip_version",
     "vqhip_multi_create", "vqhip_multi_destroy", "vqhip_multi_last_error", "vqhip_multi_encode", "vqhip_multi_decode",
     "vqhip_decompress_file", "vqhip_compress_file", "vqhip_reserve",
+    "vqhip_train_begin", "vqhip_train_vq_stats_device", "vqhip_train_vq_update_device", "vqhip_train_get_state", "vqhip_train_set_state",
+    "vqhip_train_commit",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -140,6 +142,12 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_decode_leaves.argtypes = [vp, vp, i64, vp]
     lib.vqhip_set_chunk_leaves.argtypes = [vp, i64]
     lib.vqhip_reserve.argtypes = [vp, i64]
+    lib.vqhip_train_begin.argtypes = [vp, vp, vp]
+    lib.vqhip_train_vq_stats_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    lib.vqhip_train_vq_update_device.argtypes = [vp, vp, ctypes.c_float, ctypes.c_float, vp]
+    lib.vqhip_train_get_state.argtypes = [vp, vp, vp, vp]
+    lib.vqhip_train_set_state.argtypes = [vp, vp, vp, vp]
+    lib.vqhip_train_commit.argtypes = [vp]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
     lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
     lib.vqhip_debug_enable.argtypes = [vp, ci]
@@ -296,6 +304,30 @@ class HipCodec:
 
     def set_chunk_leaves(self, n: int):
         self._check(self._lib.vqhip_set_chunk_leaves(self._h, n))
+
+    # ---- codebook training (VectorQuantizerEMA in training mode; see vqvdb_amd/codebook_training.py) ----
+    def train_begin(self, cluster_size: Optional[np.ndarray] = None, embed_avg: Optional[np.ndarray] = None):
+        cs = None if cluster_size is None else np.ascontiguousarray(cluster_size, dtype=np.float32).reshape(256)
+        av = None if embed_avg is None else np.ascontiguousarray(embed_avg, dtype=np.float32).reshape(256, 128)
+        self._check(self._lib.vqhip_train_begin(self._h, None if cs is None else cs.ctypes.data, None if av is None else av.ctypes.data))
+
+    def train_vq_stats_device(self, leaves_ptr: int, n: int, stats_ptr: int, idx_ptr: int = 0, latent_ptr: int = 0, stream: int = 0):
+        self._check(self._lib.vqhip_train_vq_stats_device(self._h, leaves_ptr, n, stats_ptr, idx_ptr or None, latent_ptr or None, stream or None))
+
+    def train_vq_update_device(self, stats_ptr: int, decay: float = 0.95, eps: float = 1e-4, stream: int = 0):
+        self._check(self._lib.vqhip_train_vq_update_device(self._h, stats_ptr, decay, eps, stream or None))
+
+    def train_get_state(self):
+        emb, cs, avg = np.empty((256, 128), np.float32), np.empty(256, np.float32), np.empty((256, 128), np.float32)
+        self._check(self._lib.vqhip_train_get_state(self._h, emb.ctypes.data, cs.ctypes.data, avg.ctypes.data))
+        return {"embedding": emb, "cluster_size": cs, "embed_avg": avg}
+
+    def train_set_state(self, embedding=None, cluster_size=None, embed_avg=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (embedding, cluster_size, embed_avg)]
+        self._check(self._lib.vqhip_train_set_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+
+    def train_commit(self):
+        self._check(self._lib.vqhip_train_commit(self._h))
 
     def reserve(self, n: int):
         self._check(self._lib.vqhip_reserve(self._h, n))

@@ -22,6 +22,7 @@
 
 #include "../../include/vqvdb_hip.h"
 #include "vq_kernels.h"
+#include "vq_train_kernels.h"
 
 namespace {
 
@@ -103,6 +104,14 @@ struct vqhip_codec {
     std::vector<KernelTimer> timers;
 
     bool debug = false;
+
+    // codebook training (vqhip_train_*): host copies of what the inference tables are rebuilt from, live state flag,
+    // latent / index scratch for one training batch
+    std::vector<float> h_proj_w, h_proj_b;
+    bool training = false, tables_stale = false;
+    float* tr_z = nullptr;
+    uint8_t* tr_idx = nullptr;
+    int64_t tr_leaves = 0;
 };
 
 namespace {
@@ -333,6 +342,11 @@ int upload_i(vqhip_codec* c, const char* name, const std::vector<int>& v)
 int upload(vqhip_codec* c, const char* name, const std::vector<float>& v)
 {
     float* d = nullptr;
+    auto it = c->dw.find(name);
+    if (it != c->dw.end()) {  // refresh of a derived table (same size by construction)
+        HIPCHK(c, hipMemcpy(it->second, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return VQHIP_OK;
+    }
     HIPCHK(c, hipMalloc(&d, v.size() * sizeof(float)));
     HIPCHK(c, hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     c->dw[name] = d;
@@ -341,6 +355,31 @@ int upload(vqhip_codec* c, const char* name, const std::vector<float>& v)
 int upload(vqhip_codec* c, const char* name, const PackTensor* t)
 {
     return upload(c, name, std::vector<float>(t->data, t->data + t->count));
+}
+
+// Projection folded into the codebook (contract: oracle vqfold_build): Ep = E P in fp64 (j ascending),
+// c_k = sum e^2 - 2 sum b e, both rounded to fp32 once.  E = codebook [256][128] on the host.
+int build_vq_fold(vqhip_codec* c, const float* E)
+{
+    std::vector<float> ep(256 * 32), ck(256);
+    const float* P = c->h_proj_w.data();  // [128][32]
+    const float* pb = c->h_proj_b.data();
+    for (int k = 0; k < 256; ++k) {
+        for (int ch = 0; ch < 32; ++ch) {
+            double acc = 0.0;
+            for (int jx = 0; jx < 128; ++jx) acc = __builtin_fma((double)E[k * 128 + jx], (double)P[jx * 32 + ch], acc);
+            ep[k * 32 + ch] = (float)acc;
+        }
+        double cc = 0.0, bb = 0.0;
+        for (int jx = 0; jx < 128; ++jx) {
+            cc = __builtin_fma((double)E[k * 128 + jx], (double)E[k * 128 + jx], cc);
+            bb = __builtin_fma((double)pb[jx], (double)E[k * 128 + jx], bb);
+        }
+        ck[k] = (float)(cc - 2.0 * bb);
+    }
+    int rc;
+    if ((rc = upload(c, "vq.ep", frag32(ep.data(), 256, 32, 1)))) return rc;
+    return upload(c, "vq.ck", dfrag32(ck.data(), 256));
 }
 
 // Folded decoder tail: up_conv (64->256,k3 @4^3) -> PixelShuffle3D(2) -> final (32->1,k3 @8^3) is one
@@ -462,28 +501,10 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
     UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
     UP("cb", cb)
-    {
-        // projection folded into the codebook (contract: oracle vqfold_build): Ep = E P in fp64 (j ascending),
-        // c_k = sum e^2 - 2 sum b e, both rounded to fp32 once
-        std::vector<float> ep(256 * 32), ck(256);
-        const float* E = cb->data;
-        const float* P = epw->data;   // [128][32]
-        for (int k = 0; k < 256; ++k) {
-            for (int ch = 0; ch < 32; ++ch) {
-                double acc = 0.0;
-                for (int jx = 0; jx < 128; ++jx) acc = __builtin_fma((double)E[k * 128 + jx], (double)P[jx * 32 + ch], acc);
-                ep[k * 32 + ch] = (float)acc;
-            }
-            double cc = 0.0, bb = 0.0;
-            for (int jx = 0; jx < 128; ++jx) {
-                cc = __builtin_fma((double)E[k * 128 + jx], (double)E[k * 128 + jx], cc);
-                bb = __builtin_fma((double)epb->data[jx], (double)E[k * 128 + jx], bb);
-            }
-            ck[k] = (float)(cc - 2.0 * bb);
-        }
-        UP("vq.ep", frag32(ep.data(), 256, 32, 1))
-        UP("vq.ck", dfrag32(ck.data(), 256))
-    }
+    c->h_proj_w.assign(epw->data, epw->data + 128 * 32);
+    c->h_proj_b.assign(epb->data, epb->data + 128);
+    UP("tr.wproj", frag32(epw->data, 128, 32, 1)) UP("tr.bproj", dfrag32(epb->data, 128))
+    if ((rc = build_vq_fold(c, cb->data))) return rc;
 #undef UP
     if ((rc = upload_i(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
     if ((rc = upload_i(c, "steps.rowgroups8_4", steps_rowgroups8(4)))) return rc;
@@ -595,16 +616,20 @@ constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, res
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
 constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 
+constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + projection A-fragments (144 KB)
+
 int init_kernel_attrs(vqhip_codec* c)
 {
     int rc;
+    if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
+    if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, k_enc_down, LDS_ENC_DOWN))) return rc;
     if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
     return VQHIP_OK;
 }
 
-int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, hipStream_t s)
+int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, hipStream_t s, float* d_latent = nullptr)
 {
     int rc = ensure_workspace(c, n);
     if (rc) return rc;
@@ -662,6 +687,17 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.out_csum = a["csum"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
         L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+    }
+    if (d_latent) {
+        // training forward: latent materialised, reference-faithful distance against the live codebook
+        L.run("train_codebook_frag", [&] { hipLaunchKernelGGL(codebook_frag_k, dim3(33), dim3(256), 0, s, w["cb"], w["tr.efrag"], w["tr.ee"]); });
+        LatentArgs A{};
+        A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+        A.wproj = w["tr.wproj"], A.bproj = w["tr.bproj"], A.efrag = w["tr.efrag"], A.ee_frag = w["tr.ee"];
+        A.idx = d_idx, A.z = d_latent, A.n_leaves = n, A.n_tiles = nt;
+        if (nt >= 1024) L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<8>, dim3(g8), dim3(512), LDS_LATENT, s, A); });
+        else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2), dim3(128), LDS_LATENT, s, A); });
+        return L.rc;
     }
     {
         VqArgs A{};
@@ -790,6 +826,26 @@ void host_parallel_copy(void* dst, const void* src, size_t bytes)
     }, 4);
 }
 
+int refresh_tables(vqhip_codec* c)
+{
+    std::vector<float> E(256 * 128);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(E.data(), c->dw["cb"], E.size() * sizeof(float), hipMemcpyDeviceToHost));
+    int rc = build_vq_fold(c, E.data());
+    if (rc) return rc;
+    hipLaunchKernelGGL(build_stem_lut_k, dim3(27 * 256), dim3(64), 0, c->stream, c->dw["ds.w"], c->dw["cb"], c->dw["ds.lut"]);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tables_stale = false;
+    return VQHIP_OK;
+}
+
+// inference entry points after codebook training: the folded VQ tables and the decoder stem table follow the live codebook
+int ensure_tables(vqhip_codec* c)
+{
+    return c->tables_stale ? refresh_tables(c) : VQHIP_OK;
+}
+
 // Host-side pipeline shared by every entry point that takes host memory (the path the reference orchestrator
 // calls, VQVAECodec.cpp:120,178).  Chunk i: produce() -> H2D on s_in -> kernels on the compute stream -> D2H into
 // pinned memory on s_out; consume() of chunk i-1 runs on the calling thread while the GPU works on chunk i.
@@ -804,7 +860,8 @@ int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool w
 {
     HIPCHK(c, hipSetDevice(c->device));
     step = std::min(step > 0 ? std::min(step, c->chunk) : c->chunk, n);
-    int rc = ensure_io(c, step);
+    int rc = ensure_tables(c);
+    if (!rc) rc = ensure_io(c, step);
     if (rc) return rc;
     const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
     if (want_stage && (rc = ensure_stage(c, step))) return rc;
@@ -982,6 +1039,8 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->dw) hipFree(kv.second);
     if (c->ws) hipFree(c->ws);
+    if (c->tr_z) hipFree(c->tr_z);
+    if (c->tr_idx) hipFree(c->tr_idx);
     for (int i = 0; i < 2; ++i) {
         if (c->dev_leaves[i]) hipFree(c->dev_leaves[i]);
         if (c->dev_idx[i]) hipFree(c->dev_idx[i]);
@@ -1033,6 +1092,7 @@ int vqhip_encode_device(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_
     if (!c) return VQHIP_ERR_INVALID;
     if (!d_leaves || !d_idx || n < 1) return fail(c, VQHIP_ERR_INVALID, "encode: null pointer or n_leaves < 1");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int trc = ensure_tables(c)) return trc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int64_t m = std::min(c->chunk, n - o);
@@ -1047,6 +1107,7 @@ int vqhip_decode_device(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* 
     if (!c) return VQHIP_ERR_INVALID;
     if (!d_idx || !d_out || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode: null pointer or n_leaves < 1");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int trc = ensure_tables(c)) return trc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     for (int64_t o = 0; o < n; o += c->chunk) {
         const int64_t m = std::min(c->chunk, n - o);
@@ -1295,6 +1356,103 @@ int vqhip_compress_file(vqhip_codec* c, const char* path, const vqhip_grid_sourc
     st.wall_s = now_s() - t_start;
     if (stats) *stats = st;
     return VQHIP_OK;
+}
+
+// ---- codebook training (stage 1): VectorQuantizerEMA.forward in training mode, VQVAE_v2.py:107-156 ----
+int vqhip_train_begin(vqhip_codec* c, const float* cluster_size, const float* embed_avg)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (!c->training) {
+        if ((rc = upload(c, "tr.efrag", std::vector<float>(16 * 8 * 64 * 4, 0.0f)))) return rc;
+        if ((rc = upload(c, "tr.ee", std::vector<float>(256, 0.0f)))) return rc;
+    }
+    std::vector<float> cs(256, 1.0f), avg(256 * 128);  // reference initial buffers (VQVAE_v2.py:104-105)
+    if (cluster_size) cs.assign(cluster_size, cluster_size + 256);
+    if (embed_avg) avg.assign(embed_avg, embed_avg + 256 * 128);
+    else HIPCHK(c, hipMemcpy(avg.data(), c->dw["cb"], avg.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if ((rc = upload(c, "tr.cs", cs))) return rc;
+    if ((rc = upload(c, "tr.avg", avg))) return rc;
+    c->training = true;
+    return VQHIP_OK;
+}
+
+int vqhip_train_vq_stats_device(vqhip_codec* c, const float* d_leaves, int64_t n, float* d_stats, uint8_t* d_idx, float* d_latent, void* stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!c->training) return fail(c, VQHIP_ERR_INVALID, "train_vq_stats: call vqhip_train_begin first");
+    if (!d_leaves || !d_stats || n < 1) return fail(c, VQHIP_ERR_INVALID, "train_vq_stats: null pointer or n_leaves < 1");
+    if (n > c->chunk) return fail(c, VQHIP_ERR_INVALID, "train_vq_stats: a training batch may not exceed the chunk size (" + std::to_string(c->chunk) + " leaves)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if ((!d_latent || !d_idx) && c->tr_leaves < n) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->tr_z) hipFree(c->tr_z);
+        if (c->tr_idx) hipFree(c->tr_idx);
+        c->tr_z = nullptr, c->tr_idx = nullptr, c->tr_leaves = 0;
+        HIPCHK(c, hipMalloc(&c->tr_z, (size_t)n * 64 * 128 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->tr_idx, (size_t)n * 64));
+        c->tr_leaves = n;
+    }
+    float* z = d_latent ? d_latent : c->tr_z;
+    uint8_t* idx = d_idx ? d_idx : c->tr_idx;
+    int rc = encode_chunk(c, d_leaves, n, idx, s, z);
+    if (rc) return rc;
+    Launcher L{c, s, n};
+    L.run("train_vq_ema_stats", [&] { hipLaunchKernelGGL(vq_ema_stats_k, dim3(256), dim3(1024), 0, s, z, idx, c->dw["cb"], n * 64, d_stats); });
+    return L.rc;
+}
+
+int vqhip_train_vq_update_device(vqhip_codec* c, const float* d_stats, float decay, float eps, void* stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!c->training) return fail(c, VQHIP_ERR_INVALID, "train_vq_update: call vqhip_train_begin first");
+    if (!d_stats || !(decay >= 0.0f && decay <= 1.0f) || !(eps > 0.0f)) return fail(c, VQHIP_ERR_INVALID, "train_vq_update: null stats, decay outside [0,1] or eps <= 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const float alpha = (float)(1.0 - (double)decay);
+    Launcher L{c, s, 0};
+    L.run("train_vq_ema_update", [&] {
+        hipLaunchKernelGGL(vq_ema_update_k, dim3(256), dim3(128), 0, s, d_stats, decay, alpha, eps, c->dw["tr.cs"], c->dw["tr.avg"], c->dw["cb"]);
+    });
+    c->tables_stale = true;
+    return L.rc;
+}
+
+int vqhip_train_get_state(vqhip_codec* c, float* embedding, float* cluster_size, float* embed_avg)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!c->training && (cluster_size || embed_avg)) return fail(c, VQHIP_ERR_INVALID, "train_get_state: call vqhip_train_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (embedding) HIPCHK(c, hipMemcpy(embedding, c->dw["cb"], 256 * 128 * sizeof(float), hipMemcpyDeviceToHost));
+    if (cluster_size) HIPCHK(c, hipMemcpy(cluster_size, c->dw["tr.cs"], 256 * sizeof(float), hipMemcpyDeviceToHost));
+    if (embed_avg) HIPCHK(c, hipMemcpy(embed_avg, c->dw["tr.avg"], 256 * 128 * sizeof(float), hipMemcpyDeviceToHost));
+    return VQHIP_OK;
+}
+
+int vqhip_train_set_state(vqhip_codec* c, const float* embedding, const float* cluster_size, const float* embed_avg)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!c->training && (cluster_size || embed_avg)) return fail(c, VQHIP_ERR_INVALID, "train_set_state: call vqhip_train_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (embedding) {
+        HIPCHK(c, hipMemcpy(c->dw["cb"], embedding, 256 * 128 * sizeof(float), hipMemcpyHostToDevice));
+        c->tables_stale = true;
+    }
+    if (cluster_size) HIPCHK(c, hipMemcpy(c->dw["tr.cs"], cluster_size, 256 * sizeof(float), hipMemcpyHostToDevice));
+    if (embed_avg) HIPCHK(c, hipMemcpy(c->dw["tr.avg"], embed_avg, 256 * 128 * sizeof(float), hipMemcpyHostToDevice));
+    return VQHIP_OK;
+}
+
+int vqhip_train_commit(vqhip_codec* c)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return c->tables_stale ? refresh_tables(c) : VQHIP_OK;
 }
 
 // ---- in-process multi-GPU front end: one codec + one host thread per device, contiguous leaf ranges ----

@@ -1,0 +1,237 @@
+// vq_train_kernels.h — codebook-training kernels (stage 1): the training-mode forward of
+// VectorQuantizerEMA (python/VQVAE_v2.py:107-156) on encoder outputs, for gfx950.
+//
+//   latent_assign_k   z = proj(gate * x11) + b materialised (flat [row][128], row = leaf*64 + pos, the reference's
+//                     `flat` view, :113-114) and assigned with the reference's expanded distance against the LIVE
+//                     codebook (:117-124): the arithmetic of the oracle's "faithful" path.
+//   vq_ema_stats_k    encodings_sum, dw = encodings^T @ flat, sum (z - e)^2   (:134-137,146) without one-hots:
+//                     one workgroup per code scans the indices and adds up its rows in a fixed order (deterministic,
+//                     no atomics); 16 row segments per code, each an ascending fp32 chain, segments added ascending.
+//   vq_ema_update_k   cluster_size / embed_avg EMA and embedding = embed_avg / clamp(cluster_size, eps) (:135-144)
+//   codebook_frag_k   live codebook -> MFMA A-fragment order + code norms for latent_assign_k
+#pragma once
+#include "vq_device.h"
+
+#define VQ_STATS_COUNTS 0
+#define VQ_STATS_DW 256
+#define VQ_STATS_SQ (256 + 256 * 128)
+#define VQ_STATS_ROWS (256 + 256 * 128 + 256)
+#define VQ_STATS_FLOATS (256 + 256 * 128 + 256 + 1)
+
+// efrag[(u*8+ct)*64+lane][i] = E[32ct + (lane&31)][8u + 4(lane>>5) + i];  ee_frag[(ct*2+q)*16+r] = ||E[32ct+(r&3)+8(r>>2)+4q]||^2
+__global__ __launch_bounds__(256) void codebook_frag_k(const float* __restrict__ E, float* __restrict__ efrag, float* __restrict__ ee_frag)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 16 * 8 * 64) {
+        const int u = t / (8 * 64), ct = (t / 64) % 8, lane = t % 64;
+        const float* src = E + (32 * ct + (lane & 31)) * 128 + 8 * u + 4 * (lane >> 5);
+        ((f32x4*)efrag)[t] = (f32x4){src[0], src[1], src[2], src[3]};
+    } else if (t < 16 * 8 * 64 + 256) {
+        const int f = t - 16 * 8 * 64;
+        const int ct = f / 32, q = (f / 16) % 2, r = f % 16;
+        const float* e = E + (32 * ct + (r & 3) + 8 * (r >> 2) + 4 * q) * 128;
+        float s = 0.0f;
+        for (int c = 0; c < 128; ++c) s = __builtin_fmaf(e[c], e[c], s);
+        ee_frag[f] = s;
+    }
+}
+
+struct LatentArgs {
+    const float* in;        // x11 L4 [tile][64][8][32][4]
+    const float* se_csum;   // [tile][32][32]
+    const float* se_fc0;    // [8][32]
+    const float* se_fc2;    // [32][8]
+    const float* wproj;     // frag [u=4][mt=4][64][4]
+    const float* bproj;     // D-fragment order [(mt*2+q)*16 + r]
+    const float* efrag;     // frag [u=16][ct=8][64][4]
+    const float* ee_frag;   // [(ct*2+q)*16 + r]
+    uint8_t* idx;           // [n_leaves][64]
+    float* z;               // flat [n_leaves*64][128]
+    int64_t n_leaves;
+    int n_tiles;
+};
+
+// One wave per 32-leaf tile.  Per position: z (128 ch) by 64 MFMAs with the gated activations as B operand; z is then
+// directly the B operand of the distance GEMM (D-layout rows (r&3)+8(r>>2)+4q give the contract's "P8" k-order).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void latent_assign_k(LatentArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* ldsE = (f32x4*)smem_raw;          // 16*8*64 float4 = 128 KB
+    f32x4* ldsP = ldsE + 16 * 8 * 64;        // 4*4*64 float4  = 16 KB
+    for (int i = threadIdx.x; i < 16 * 8 * 64; i += NW * 64) ldsE[i] = ((const f32x4*)A.efrag)[i];
+    for (int i = threadIdx.x; i < 4 * 4 * 64; i += NW * 64) ldsP[i] = ((const f32x4*)A.wproj)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * NW + wave;
+    if (tile >= A.n_tiles) return;
+    const int j = lane & 31, q = lane >> 5;
+    float gate[4][4];
+    {
+        float hid[8], gall[32];
+        se_hidden<32>(A.se_csum + (size_t)tile * 32 * 32 + j, A.se_fc0, hid);
+        se_gates<32>(hid, A.se_fc2, gall);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
+    }
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 8 * 32 + q * 32 + j;
+    const f32x4* bp4 = (const f32x4*)A.bproj;
+    const f32x4* ee4 = (const f32x4*)A.ee_frag;
+    const int64_t leaf = (int64_t)tile * 32 + j;
+    const bool live = leaf < A.n_leaves;
+    for (int p = 0; p < 64; ++p) {
+        f32x16 z[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[t][r] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 b = in4[((size_t)p * 8 + 2 * u) * 32];
+            b.x = b.x * gate[u][0];
+            b.y = b.y * gate[u][1];
+            b.z = b.z * gate[u][2];
+            b.w = b.w * gate[u][3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 w = ldsP[(u * 4 + t) * 64 + lane];
+                z[t] = mfma32(w.x, b.x, z[t]);
+                z[t] = mfma32(w.y, b.y, z[t]);
+                z[t] = mfma32(w.z, b.z, z[t]);
+                z[t] = mfma32(w.w, b.w, z[t]);
+            }
+        }
+        float zzp = 0.0f;
+        f32x4* zrow = (f32x4*)(A.z + ((size_t)leaf * 64 + p) * 128);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = bp4[(t * 2 + q) * 4 + g];
+                z[t][4 * g + 0] = z[t][4 * g + 0] + bias.x;
+                z[t][4 * g + 1] = z[t][4 * g + 1] + bias.y;
+                z[t][4 * g + 2] = z[t][4 * g + 2] + bias.z;
+                z[t][4 * g + 3] = z[t][4 * g + 3] + bias.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zzp = __builtin_fmaf(z[t][4 * g + i], z[t][4 * g + i], zzp);
+                if (live) {  // channels 32t + 8g + 4q .. +3 of this leaf's row
+                    f32x4 v;
+                    v.x = z[t][4 * g + 0], v.y = z[t][4 * g + 1], v.z = z[t][4 * g + 2], v.w = z[t][4 * g + 3];
+                    zrow[8 * t + 2 * g + q] = v;
+                }
+            }
+        const float zzo = __shfl_xor(zzp, 32, 64);
+        const float zz = q == 0 ? zzp + zzo : zzo + zzp;  // partial(c&4==0) + partial(c&4!=0)
+        float best = __builtin_inff();
+        int bk = 0;
+        for (int ct = 0; ct < 8; ++ct) {
+            f32x4 eev[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) eev[g] = ee4[(ct * 2 + q) * 4 + g];
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 e = ldsE[((4 * t + g) * 8 + ct) * 64 + lane];
+                    d = mfma32(e.x, z[t][4 * g + 0], d);
+                    d = mfma32(e.y, z[t][4 * g + 1], d);
+                    d = mfma32(e.z, z[t][4 * g + 2], d);
+                    d = mfma32(e.w, z[t][4 * g + 3], d);
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);  // keep LDS reads from piling up (VGPR budget)
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ee = eev[g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float een = i == 0 ? ee.x : (i == 1 ? ee.y : (i == 2 ? ee.z : ee.w));
+                    const float t1 = zz + een;
+                    const float dist = t1 - 2.0f * d[4 * g + i];
+                    const int k = 32 * ct + i + 8 * g + 4 * q;
+                    if (dist < best) {
+                        best = dist;
+                        bk = k;
+                    }
+                }
+            }
+        }
+        const float ob = __shfl_xor(best, 32, 64);
+        const int ok = __shfl_xor(bk, 32, 64);
+        if (ob < best || (ob == best && ok < bk)) bk = ok;
+        if (q == 0 && live) A.idx[leaf * 64 + p] = (uint8_t)bk;
+    }
+}
+
+// One workgroup (16 waves) per code k.  Wave w scans rows [w*R/16, (w+1)*R/16) (R = 64*n_leaves, a multiple of 64);
+// lane l owns channels 2l, 2l+1.  Output (local to this rank, summed across ranks by the host's all-reduce):
+//   stats[COUNTS+k], stats[DW + k*128 + c], stats[SQ+k] = sum over the code's rows and channels of (z-e)^2
+__global__ __launch_bounds__(1024) void vq_ema_stats_k(const float* __restrict__ z, const uint8_t* __restrict__ idx, const float* __restrict__ E,
+                                                        int64_t n_rows, float* __restrict__ stats)
+{
+    __shared__ float part[16][128];
+    __shared__ float sqp[16][64];
+    __shared__ int cntp[16];
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t seg = n_rows / 16;
+    const int64_t r0 = wave * seg, r1 = r0 + seg;
+    const float e0 = E[k * 128 + 2 * lane], e1 = E[k * 128 + 2 * lane + 1];
+    float a0 = 0.0f, a1 = 0.0f, sq = 0.0f;
+    int cnt = 0;
+    for (int64_t r = r0; r < r1; r += 64) {
+        const int64_t rr = r + lane;
+        const bool hit = rr < r1 && idx[rr] == (uint8_t)k;
+        unsigned long long m = __ballot(hit);
+        cnt += __popcll(m);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const float2 v = *(const float2*)(z + (size_t)(r + b) * 128 + 2 * lane);
+            a0 = a0 + v.x;
+            a1 = a1 + v.y;
+            const float d0 = v.x - e0, d1 = v.y - e1;
+            sq = __builtin_fmaf(d0, d0, sq);
+            sq = __builtin_fmaf(d1, d1, sq);
+        }
+    }
+    part[wave][2 * lane] = a0;
+    part[wave][2 * lane + 1] = a1;
+    sqp[wave][lane] = sq;
+    if (lane == 0) cntp[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float s = 0.0f;
+        for (int w = 0; w < 16; ++w) s = s + part[w][threadIdx.x];
+        stats[VQ_STATS_DW + k * 128 + threadIdx.x] = s;
+    } else if (threadIdx.x == 128) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w)
+            for (int l = 0; l < 64; ++l) s += (double)sqp[w][l];
+        stats[VQ_STATS_SQ + k] = (float)s;
+    } else if (threadIdx.x == 192) {
+        int s = 0;
+        for (int w = 0; w < 16; ++w) s += cntp[w];
+        stats[VQ_STATS_COUNTS + k] = (float)s;
+        if (k == 0) stats[VQ_STATS_ROWS] = (float)n_rows;
+    }
+}
+
+// EMA update from the (all-reduced) statistics; one workgroup per code, one thread per channel.
+__global__ __launch_bounds__(128) void vq_ema_update_k(const float* __restrict__ stats, float decay, float alpha, float eps,
+                                                        float* __restrict__ cluster_size, float* __restrict__ embed_avg, float* __restrict__ embedding)
+{
+    const int k = blockIdx.x, c = threadIdx.x;
+    const float cs = __builtin_fmaf(alpha, stats[VQ_STATS_COUNTS + k], cluster_size[k] * decay);
+    const float avg = __builtin_fmaf(alpha, stats[VQ_STATS_DW + k * 128 + c], embed_avg[k * 128 + c] * decay);
+    embed_avg[k * 128 + c] = avg;
+    embedding[k * 128 + c] = avg / (cs < eps ? eps : cs);
+    __syncthreads();  // every thread has read cluster_size[k]
+    if (c == 0) cluster_size[k] = cs;
+}
