@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the codebook-training leg (BASELINE configs[4], quantizer part)")
     ap.add_argument("--host-path", action="store_true", help="also time the host-pointer C ABI (pageable memory in/out, PCIe included)")
     args = ap.parse_args()
 
@@ -191,6 +192,32 @@ def main():
     enc_lps = world * args.steps * BATCH / t_enc
     dec_lps = world * args.steps * BATCH / t_dec
 
+    # Codebook (EMA) training steps, the quantizer part of BASELINE configs[4]: per-rank batches of 2048 leaves (the
+    # reference's BATCH_SIZE, python/training.py:49) and of 65536 leaves; statistics all-reduced over RCCL when N > 1.
+    train = None
+    if not args.no_train:
+        try:
+            from vqvdb_amd.codebook_training import CodebookTrainer
+            tcodec = HipCodec(weightpack.dumps(W), device_id=local)   # its own handle: training rewrites the codebook
+            tcodec.set_chunk_leaves(BATCH)
+            trainer = CodebookTrainer(tcodec, device=str(device))
+            train = {"note": "VectorQuantizerEMA training-mode step on encoder outputs (encoder forward + latent + assign + "
+                             "statistics + all-reduce + EMA update); encoder/decoder weights frozen; not the headline value",
+                     "collective": f"all_reduce(SUM) of 33281 fp32 over {world} rank(s), RCCL" if dist else "none (1 rank)"}
+            ksteps = max(2, min(args.steps, 8))
+            for per_rank in (2048, BATCH):
+                x = leaves[0][:per_rank]
+                for _ in range(2):
+                    trainer.step(x, want_metrics=False)
+                t_tr = timed(lambda s: trainer.step(x, want_metrics=False), ksteps, dist, device)
+                last = trainer.step(x)
+                train[f"per_rank_batch_{per_rank}"] = {"leaves_per_s": round(world * ksteps * per_rank / t_tr, 1),
+                                                        "ms_per_step": round(t_tr / ksteps * 1e3, 4), "steps": ksteps,
+                                                        "vq_loss": round(last["vq_loss"], 6), "perplexity": round(last["perplexity"], 3)}
+            tcodec.close()
+        except Exception as e:  # noqa: BLE001 — the training leg must never take the headline measurement down
+            train = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         ek = profile_pass(codec, enc, min(args.steps, 4), device, "flops_per_leaf")
         dk = profile_pass(codec, dec, min(args.steps, 4), device, "flops_per_leaf")
@@ -235,6 +262,7 @@ def main():
             "flop_per_leaf": {"encode_nominal": ENC_FLOP, "encode_effective": ENC_FLOP_EFF, "decode_nominal": DEC_FLOP, "decode_effective": DEC_FLOP_EFF},
             "parity_sample": parity,
             "host_path": host,
+            "codebook_training": train,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:

@@ -762,10 +762,10 @@ int vqo_decode_ex(const float* const* W, const uint8_t* idx, int64_t B, float* o
  * (vqvdb_amd/csrc/vq_train_kernels.h) follow the same operation order:
  *   assign : dist_k = (zz + ee_k) - 2 * dot_k as in the "faithful" encode path above
  *            (zz = chain over channels with (c&4)==0 + chain over the others, dot in "P8" order), first minimum
- *   stats  : rows split into 16 equal contiguous segments; per (code, segment, channel) an ascending fp32
- *            chain of the member rows; segments added ascending in fp32 from 0 -> dw (= encodings^T @ flat, :137);
+ *   stats  : rows cut into segments of 8192 consecutive rows (last one short); per (code, segment, channel) an ascending
+ *            fp32 chain of the member rows; segments added ascending in fp32 from 0 -> dw (= encodings^T @ flat, :137);
  *            counts = encodings.sum(0) (:134); sq[k]: per (segment, channel pair 2l,2l+1) fp32 fmaf chain of
- *            (z-e)^2 over member rows, summed in fp64 (segment asc, pair asc) -> float
+ *            (z-e)^2 over member rows, summed in fp64 per segment (pair asc), segments added in fp64 (asc) -> float
  *   update : cluster_size = fmaf(alpha, counts, cluster_size*decay), embed_avg likewise, alpha = (float)(1-(double)decay),
  *            embedding = embed_avg / max(cluster_size, eps)                                          (:135-144)
  * stats layout: [0,256) counts | [256,256+32768) dw | [33024,33280) sq | [33280] rows
@@ -803,36 +803,37 @@ int vqo_vq_assign(const float* z, int64_t n_rows, const float* E, uint8_t* idx, 
     return 0;
 }
 
+#define VQ_SEG_ROWS 8192
 int vqo_vq_stats(const float* z, const uint8_t* idx, int64_t n_rows, const float* E, float* stats)
 {
-    if (n_rows % 16 != 0) return 1;
-    const int64_t seg = n_rows / 16;
+    const int n_seg = (int)((n_rows + VQ_SEG_ROWS - 1) / VQ_SEG_ROWS);
     for (int k = 0; k < 256; ++k) {
-        float part[16][128], sqp[16][64];
+        float dw[128];
+        double sq = 0.0;
         int cnt = 0;
-        for (int w = 0; w < 16; ++w) {
-            for (int c = 0; c < 128; ++c) part[w][c] = 0.0f;
-            for (int l = 0; l < 64; ++l) sqp[w][l] = 0.0f;
-            for (int64_t r = w * seg; r < (w + 1) * seg; ++r) {
+        for (int c = 0; c < 128; ++c) dw[c] = 0.0f;
+        for (int g = 0; g < n_seg; ++g) {
+            float part[128], sqp[64];
+            for (int c = 0; c < 128; ++c) part[c] = 0.0f;
+            for (int l = 0; l < 64; ++l) sqp[l] = 0.0f;
+            const int64_t r1 = (int64_t)(g + 1) * VQ_SEG_ROWS < n_rows ? (int64_t)(g + 1) * VQ_SEG_ROWS : n_rows;
+            for (int64_t r = (int64_t)g * VQ_SEG_ROWS; r < r1; ++r) {
                 if (idx[r] != k) continue;
                 ++cnt;
                 const float* v = z + r * 128;
-                for (int c = 0; c < 128; ++c) part[w][c] = part[w][c] + v[c];
+                for (int c = 0; c < 128; ++c) part[c] = part[c] + v[c];
                 for (int l = 0; l < 64; ++l) {
                     const float d0 = v[2 * l] - E[k * 128 + 2 * l], d1 = v[2 * l + 1] - E[k * 128 + 2 * l + 1];
-                    sqp[w][l] = fmaf(d0, d0, sqp[w][l]);
-                    sqp[w][l] = fmaf(d1, d1, sqp[w][l]);
+                    sqp[l] = fmaf(d0, d0, sqp[l]);
+                    sqp[l] = fmaf(d1, d1, sqp[l]);
                 }
             }
+            for (int c = 0; c < 128; ++c) dw[c] = dw[c] + part[c];
+            double sg = 0.0;
+            for (int l = 0; l < 64; ++l) sg += (double)sqp[l];
+            sq += sg;
         }
-        for (int c = 0; c < 128; ++c) {
-            float s = 0.0f;
-            for (int w = 0; w < 16; ++w) s = s + part[w][c];
-            stats[VQ_ST_DW + k * 128 + c] = s;
-        }
-        double sq = 0.0;
-        for (int w = 0; w < 16; ++w)
-            for (int l = 0; l < 64; ++l) sq += (double)sqp[w][l];
+        for (int c = 0; c < 128; ++c) stats[VQ_ST_DW + k * 128 + c] = dw[c];
         stats[VQ_ST_SQ + k] = (float)sq;
         stats[k] = (float)cnt;
     }

@@ -42,7 +42,7 @@ def _gpu_stats(codec, leaves):
 def test_training_step_bit_exact_vs_oracle(tcodec, oracle, weights):
     state = {"embedding": weights["quantizer.embedding"].copy(), "cluster_size": np.ones(K, np.float32),
              "embed_avg": weights["quantizer.embedding"].copy()}
-    for step, n in enumerate((200, 33, 1)):                      # ragged tiles; steps 1, 2 run against the LIVE codebook
+    for step, n in enumerate((1000, 33, 1)):   # ragged tiles, 8 row segments (last one short); steps 1, 2 use the LIVE codebook
         leaves = synth.make_leaves(n, seed=31 + step)
         stats, idx, z = _gpu_stats(tcodec, leaves)
         oz = oracle.latent(leaves, threads=8)

@@ -112,6 +112,8 @@ struct vqhip_codec {
     float* tr_z = nullptr;
     uint8_t* tr_idx = nullptr;
     int64_t tr_leaves = 0;
+    char* tr_part = nullptr;   // per-(code, row segment) partial statistics
+    size_t tr_part_bytes = 0;
 };
 
 namespace {
@@ -1041,6 +1043,7 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->ws) hipFree(c->ws);
     if (c->tr_z) hipFree(c->tr_z);
     if (c->tr_idx) hipFree(c->tr_idx);
+    if (c->tr_part) hipFree(c->tr_part);
     for (int i = 0; i < 2; ++i) {
         if (c->dev_leaves[i]) hipFree(c->dev_leaves[i]);
         if (c->dev_idx[i]) hipFree(c->dev_idx[i]);
@@ -1395,12 +1398,30 @@ int vqhip_train_vq_stats_device(vqhip_codec* c, const float* d_leaves, int64_t n
         HIPCHK(c, hipMalloc(&c->tr_idx, (size_t)n * 64));
         c->tr_leaves = n;
     }
+    {
+        const size_t need = (size_t)256 * ((n * 64 + VQ_SEG_ROWS - 1) / VQ_SEG_ROWS) * (128 * sizeof(float) + sizeof(double) + sizeof(int));
+        if (c->tr_part_bytes < need) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->tr_part) hipFree(c->tr_part);
+            c->tr_part = nullptr, c->tr_part_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->tr_part, need));
+            c->tr_part_bytes = need;
+        }
+    }
     float* z = d_latent ? d_latent : c->tr_z;
     uint8_t* idx = d_idx ? d_idx : c->tr_idx;
     int rc = encode_chunk(c, d_leaves, n, idx, s, z);
     if (rc) return rc;
+    const int64_t rows = n * 64;
+    const int n_seg = (int)((rows + VQ_SEG_ROWS - 1) / VQ_SEG_ROWS);
+    float* part = reinterpret_cast<float*>(c->tr_part);
+    double* sqpart = reinterpret_cast<double*>(c->tr_part + (size_t)256 * n_seg * 128 * sizeof(float));
+    int* cntpart = reinterpret_cast<int*>(c->tr_part + (size_t)256 * n_seg * (128 * sizeof(float) + sizeof(double)));
     Launcher L{c, s, n};
-    L.run("train_vq_ema_stats", [&] { hipLaunchKernelGGL(vq_ema_stats_k, dim3(256), dim3(1024), 0, s, z, idx, c->dw["cb"], n * 64, d_stats); });
+    L.run("train_vq_ema_partials", [&] {
+        hipLaunchKernelGGL(vq_ema_partials_k, dim3(256, (n_seg + 15) / 16), dim3(1024), 0, s, z, idx, c->dw["cb"], rows, n_seg, part, sqpart, cntpart);
+    });
+    L.run("train_vq_ema_reduce", [&] { hipLaunchKernelGGL(vq_ema_reduce_k, dim3(256), dim3(128), 0, s, part, sqpart, cntpart, rows, n_seg, d_stats); });
     return L.rc;
 }
 

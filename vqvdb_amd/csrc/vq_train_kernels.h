@@ -4,9 +4,10 @@
 //   latent_assign_k   z = proj(gate * x11) + b materialised (flat [row][128], row = leaf*64 + pos, the reference's
 //                     `flat` view, :113-114) and assigned with the reference's expanded distance against the LIVE
 //                     codebook (:117-124): the arithmetic of the oracle's "faithful" path.
-//   vq_ema_stats_k    encodings_sum, dw = encodings^T @ flat, sum (z - e)^2   (:134-137,146) without one-hots:
-//                     one workgroup per code scans the indices and adds up its rows in a fixed order (deterministic,
-//                     no atomics); 16 row segments per code, each an ascending fp32 chain, segments added ascending.
+//   vq_ema_partials_k / vq_ema_reduce_k
+//                     encodings_sum, dw = encodings^T @ flat, sum (z - e)^2   (:134-137,146) without one-hots: one wave
+//                     per (code, 8192-row segment) scans the indices and adds up its member rows in ascending order,
+//                     segments are added ascending (deterministic, no atomics).
 //   vq_ema_update_k   cluster_size / embed_avg EMA and embedding = embed_avg / clamp(cluster_size, eps) (:135-144)
 //   codebook_frag_k   live codebook -> MFMA A-fragment order + code norms for latent_assign_k
 #pragma once
@@ -168,20 +169,23 @@ __global__ __launch_bounds__(NW * 64, 2) void latent_assign_k(LatentArgs A)
     }
 }
 
-// One workgroup (16 waves) per code k.  Wave w scans rows [w*R/16, (w+1)*R/16) (R = 64*n_leaves, a multiple of 64);
-// lane l owns channels 2l, 2l+1.  Output (local to this rank, summed across ranks by the host's all-reduce):
+// Statistics in two deterministic passes.  Rows are cut into segments of VQ_SEG_ROWS consecutive rows (the last may be
+// short).  Pass 1: one wave per (code k, segment): lane l owns channels 2l, 2l+1 and adds up the segment's member rows
+// in ascending order (fp32), with the squared distance to e_k as an fmaf chain; partials go to scratch.  Pass 2: one
+// workgroup per code adds the segment partials in ascending order (dw in fp32 from 0, the error in fp64).
+// Output (local to this rank, summed across ranks by the host's all-reduce):
 //   stats[COUNTS+k], stats[DW + k*128 + c], stats[SQ+k] = sum over the code's rows and channels of (z-e)^2
-__global__ __launch_bounds__(1024) void vq_ema_stats_k(const float* __restrict__ z, const uint8_t* __restrict__ idx, const float* __restrict__ E,
-                                                        int64_t n_rows, float* __restrict__ stats)
+#define VQ_SEG_ROWS 8192
+
+__global__ __launch_bounds__(1024) void vq_ema_partials_k(const float* __restrict__ z, const uint8_t* __restrict__ idx, const float* __restrict__ E,
+                                                           int64_t n_rows, int n_seg, float* __restrict__ part, double* __restrict__ sqpart,
+                                                           int* __restrict__ cntpart)
 {
-    __shared__ float part[16][128];
-    __shared__ float sqp[16][64];
-    __shared__ int cntp[16];
     const int k = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t seg = n_rows / 16;
-    const int64_t r0 = wave * seg, r1 = r0 + seg;
+    const int seg = blockIdx.y * 16 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (seg >= n_seg) return;
+    const int64_t r0 = (int64_t)seg * VQ_SEG_ROWS, r1 = r0 + VQ_SEG_ROWS < n_rows ? r0 + VQ_SEG_ROWS : n_rows;
     const float e0 = E[k * 128 + 2 * lane], e1 = E[k * 128 + 2 * lane + 1];
     float a0 = 0.0f, a1 = 0.0f, sq = 0.0f;
     int cnt = 0;
@@ -191,34 +195,59 @@ __global__ __launch_bounds__(1024) void vq_ema_stats_k(const float* __restrict__
         unsigned long long m = __ballot(hit);
         cnt += __popcll(m);
         while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            const float2 v = *(const float2*)(z + (size_t)(r + b) * 128 + 2 * lane);
-            a0 = a0 + v.x;
-            a1 = a1 + v.y;
-            const float d0 = v.x - e0, d1 = v.y - e1;
-            sq = __builtin_fmaf(d0, d0, sq);
-            sq = __builtin_fmaf(d1, d1, sq);
+            // up to four member rows in flight; accumulation stays in ascending row order
+            int b[4];
+            float2 v[4];
+            int nb = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                b[i] = m ? __builtin_ctzll(m) : -1;
+                if (m) {
+                    m &= m - 1;
+                    ++nb;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nb) v[i] = *(const float2*)(z + (size_t)(r + b[i]) * 128 + 2 * lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nb) {
+                    a0 = a0 + v[i].x;
+                    a1 = a1 + v[i].y;
+                    const float d0 = v[i].x - e0, d1 = v[i].y - e1;
+                    sq = __builtin_fmaf(d0, d0, sq);
+                    sq = __builtin_fmaf(d1, d1, sq);
+                }
         }
     }
-    part[wave][2 * lane] = a0;
-    part[wave][2 * lane + 1] = a1;
-    sqp[wave][lane] = sq;
-    if (lane == 0) cntp[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        float s = 0.0f;
-        for (int w = 0; w < 16; ++w) s = s + part[w][threadIdx.x];
-        stats[VQ_STATS_DW + k * 128 + threadIdx.x] = s;
-    } else if (threadIdx.x == 128) {
-        double s = 0.0;
-        for (int w = 0; w < 16; ++w)
-            for (int l = 0; l < 64; ++l) s += (double)sqp[w][l];
-        stats[VQ_STATS_SQ + k] = (float)s;
-    } else if (threadIdx.x == 192) {
-        int s = 0;
-        for (int w = 0; w < 16; ++w) s += cntp[w];
-        stats[VQ_STATS_COUNTS + k] = (float)s;
+    float2* dst = (float2*)(part + ((size_t)k * n_seg + seg) * 128);
+    dst[lane] = make_float2(a0, a1);
+    // per-segment error: lanes ascending, fp64
+    double s = 0.0;
+    for (int l = 0; l < 64; ++l) s += (double)__shfl(sq, l, 64);
+    if (lane == 0) {
+        sqpart[(size_t)k * n_seg + seg] = s;
+        cntpart[(size_t)k * n_seg + seg] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(128) void vq_ema_reduce_k(const float* __restrict__ part, const double* __restrict__ sqpart, const int* __restrict__ cntpart,
+                                                        int64_t n_rows, int n_seg, float* __restrict__ stats)
+{
+    const int k = blockIdx.x, c = threadIdx.x;
+    float s = 0.0f;
+    for (int g = 0; g < n_seg; ++g) s = s + part[((size_t)k * n_seg + g) * 128 + c];
+    stats[VQ_STATS_DW + k * 128 + c] = s;
+    if (c == 0) {
+        double q = 0.0;
+        int n = 0;
+        for (int g = 0; g < n_seg; ++g) {
+            q += sqpart[(size_t)k * n_seg + g];
+            n += cntpart[(size_t)k * n_seg + g];
+        }
+        stats[VQ_STATS_SQ + k] = (float)q;
+        stats[VQ_STATS_COUNTS + k] = (float)n;
         if (k == 0) stats[VQ_STATS_ROWS] = (float)n_rows;
     }
 }
