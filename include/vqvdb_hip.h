@@ -139,6 +139,13 @@ int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_lea
  * (about 0.26 MB per leaf). */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
 
+/* Batches (per internal pass) of at most `tiles` 32-leaf tiles run the position-split kernels: each layer's output
+ * slabs are spread over 4-8x more workgroups and the GroupNorm statistics are recomputed by sequential kernels, which
+ * cuts the latency of small batches (the SOP default of 64 leaves, training batches of 2048) about 5x with bit-identical
+ * results.  Default 640 tiles for encode (20480 leaves, the measured crossover) and twice that for decode; 0 disables
+ * the split path. */
+int vqhip_set_small_batch_tiles(vqhip_codec* codec, int tiles);
+
 /* Allocates up front what calls of up to n_leaves leaves (capped at the chunk size) need: the device workspace,
  * the device I/O slots and the pinned staging buffers.  Optional — every entry point allocates lazily — but it
  * moves the one-time cost (hundreds of ms for a 65536-leaf chunk: ~17 GB of HBM, 0.5 GB pinned) out of the first

@@ -314,3 +314,22 @@ def test_in_process_multi_device_sharding(codec, pack):
     with pytest.raises(RuntimeError, match="device_id out of range"):
         HipMultiCodec(pack, [0, 99])
     m.close()
+
+
+@pytest.mark.parametrize("n", [1, 64, 100, 1024, 2048])
+def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
+    """Position-split kernels + sequential statistics (default for <= 640 tiles) against the one-wave-per-tile path
+    and the oracle: indices, every stored intermediate and voxels identical."""
+    leaves = synth.make_leaves(n, seed=900 + n)
+    a, b = HipCodec(pack), HipCodec(pack)
+    b.set_small_batch_tiles(0)                      # b: classic path
+    a.debug_enable(True), b.debug_enable(True)
+    ia, ib = a.encode(leaves), b.encode(leaves)
+    assert np.array_equal(ia, ib)
+    for name in ("e_a1", "e_y4", "e_a6", "e_x7", "e_y9", "e_x11"):
+        c, p = DEBUG_SHAPES[name]
+        assert np.array_equal(_bits(a.debug_fetch(name, n, c, p)), _bits(b.debug_fetch(name, n, c, p))), name
+    if n <= 1024:
+        assert np.array_equal(ia, oracle.encode(leaves, threads=16))
+    assert np.array_equal(_bits(a.decode(ia)), _bits(b.decode(ib)))
+    a.close(), b.close()

@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "vqhip_multi_create", "vqhip_multi_destroy", "vqhip_multi_last_error", "vqhip_multi_encode", "vqhip_multi_decode",
     "vqhip_decompress_file", "vqhip_compress_file", "vqhip_reserve",
     "vqhip_train_begin", "vqhip_train_vq_stats_device", "vqhip_train_vq_update_device", "vqhip_train_get_state", "vqhip_train_set_state",
-    "vqhip_train_commit",
+    "vqhip_train_commit", "vqhip_set_small_batch_tiles",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -142,6 +142,7 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_decode_leaves.argtypes = [vp, vp, i64, vp]
     lib.vqhip_set_chunk_leaves.argtypes = [vp, i64]
     lib.vqhip_reserve.argtypes = [vp, i64]
+    lib.vqhip_set_small_batch_tiles.argtypes = [vp, ci]
     lib.vqhip_train_begin.argtypes = [vp, vp, vp]
     lib.vqhip_train_vq_stats_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.vqhip_train_vq_update_device.argtypes = [vp, vp, ctypes.c_float, ctypes.c_float, vp]
@@ -328,6 +329,9 @@ class HipCodec:
 
     def train_commit(self):
         self._check(self._lib.vqhip_train_commit(self._h))
+
+    def set_small_batch_tiles(self, tiles: int):
+        self._check(self._lib.vqhip_set_small_batch_tiles(self._h, tiles))
 
     def reserve(self, n: int):
         self._check(self._lib.vqhip_reserve(self._h, n))

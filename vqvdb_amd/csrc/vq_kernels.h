@@ -31,7 +31,23 @@ struct ConvArgs {
     int n_taps;
     int64_t n_leaves;        // OUTMODE 2 only: leaves that really exist (the last tile may be padded)
     int n_tiles;
+    // Position-split launches (small batches: too few leaf tiles to fill 1024 SIMDs): gridDim.y > 1 cuts the output
+    // od-slabs into gridDim.y ranges; od_start[od] = index of the first schedule step of slab od.  Kernels launched
+    // this way are instantiated without fused statistics (gn_stats_seq_k / csum_seq_k recompute them in the
+    // contract's sequential order from the stored output).
+    const int* od_start;
 };
+
+// slab range [od0, od1) of this workgroup for an output with NOD slabs
+template <int NOD>
+__device__ __forceinline__ void split_range(int& od0, int& od1)
+{
+    od0 = 0, od1 = NOD;
+    if (gridDim.y > 1) {
+        od0 = (int)(blockIdx.y * NOD / gridDim.y);
+        od1 = (int)((blockIdx.y + 1) * NOD / gridDim.y);
+    }
+}
 
 // One step = one output position/row and a run of 1..KWG valid taps along kw.  x: first input
 // position (or input row base), y: first tap index (weight fragment), z: output position (or
@@ -127,8 +143,11 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
         for (int k = 0; k < (MODE == 1 ? 2 : 1); ++k) st[sb][k].init();
 
     const int NS = A.n_steps;
-    int4 e = steps[0];
-    int4 en = steps[1];
+    int od0, od1;
+    split_range<8>(od0, od1);
+    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int4 e = steps[si];
+    int4 en = steps[si + 1];
     // step entry: x = centre input row base (id*8+oh)*8, y = kd, w bits 8..10 = valid kh mask
     float xn[3][8][2];
 #pragma unroll
@@ -140,8 +159,7 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
             xn[kh][ow][1] = x[rb + off[ow] + 16];
         }
     }
-    int si = 0;
-    for (int row = 0; row < 64; ++row) {
+    for (int row = od0 * 8; row < od1 * 8; ++row) {
         f32x4 acc[8][2];
 #pragma unroll
         for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
@@ -190,7 +208,9 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 f32x4 v = acc[ow][sb] + bias4;
-                if (MODE == 0) {
+                if (MODE == 2) {  // plain conv output (position-split path)
+                    out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;
+                } else if (MODE == 0) {
                     if (out4) out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;   // debug only
                     st[sb][0].add(v.x);
                     st[sb][0].add(v.y);
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
                 }
             }
     }
+    if (MODE == 2) return;
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
         if (MODE == 0) {
@@ -349,13 +370,15 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
     st[0].init();
     st[1].init();
     const int NS = A.n_steps;
-    int4 e = steps[0];
-    int4 en = steps[1];
+    int od0, od1;
+    split_range<8>(od0, od1);
+    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int4 e = steps[si];
+    int4 en = steps[si + 1];
     f32x4 xr[8];
 #pragma unroll
     for (int iw = 0; iw < 8; ++iw) xr[iw] = in4[((size_t)(e.x + iw) * 4) * 32];
-    int si = 0;
-    for (int grp = 0; grp < 64 / NR; ++grp) {  // 8 od x (8/NR) row groups
+    for (int grp = od0 * (8 / NR); grp < od1 * (8 / NR); ++grp) {  // 8 od x (8/NR) row groups
         f32x4 acc[NR][8];
 #pragma unroll
         for (int rw = 0; rw < NR; ++rw)
@@ -526,8 +549,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     const int NS = A.n_steps;
 
     // ---- pipeline prologue: table entries two ahead, operands one step ahead ----
-    int4 e = steps[0];
-    int4 en = steps[NS > 1 ? 1 : 0];
+    constexpr int PPO = NPO >= 4 ? NPO / 4 : 1;  // output positions per od-slab (4 slabs)
+    int od0, od1;
+    split_range<4>(od0, od1);
+    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int4 e = steps[si];
+    int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
     f32x4 bn[KWG][NU];
 #pragma unroll
     for (int k = 0; k < KWG; ++k) {
@@ -539,11 +566,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 #pragma unroll
         for (int pc = 0; pc < PIECES; ++pc) {
             const int piece = wave * PIECES + pc;
-            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + piece * 64);
+            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAP + piece * 64);
         }
     }
-    int si = 0;
-    for (int po = 0; po < NPO; ++po) {
+    for (int po = od0 * PPO; po < od1 * PPO; ++po) {
         f32x16 acc[NMT];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
@@ -751,15 +777,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_rows32_k(ConvArgs A, const in
     const f32x4* bf4 = (const f32x4*)A.bias_frag;
     const int NS = A.n_steps;
 
-    int4 e = steps[0];
-    int4 en = steps[NS > 1 ? 1 : 0];
+    int od0, od1;
+    split_range<SO>(od0, od1);
+    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int4 e = steps[si];
+    int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
     f32x4 xr[SI][NU];  // input row of the current step; re-loaded position by position for the next step
 #pragma unroll
     for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
         for (int u = 0; u < NU; ++u) xr[iw][u] = in4[(size_t)(e.x + iw) * (CIN / 4) * 32 + u * 64];
-    int si = 0;
-    for (int row = 0; row < SO * SO; ++row) {
+    for (int row = od0 * SO; row < od1 * SO; ++row) {
         f32x16 acc[SO][NMT];
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow)
@@ -937,10 +965,12 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
     }
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 8 * 32 + q * 32 + j;
     const int64_t leaf = (int64_t)tile * 32 + j;
+    int p0 = 0, p1 = 64;
+    if (gridDim.y > 1) p0 = (int)(blockIdx.y * 64 / gridDim.y), p1 = (int)((blockIdx.y + 1) * 64 / gridDim.y);
     f32x4 bn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bn[u] = in4[u * 64];
-    for (int p = 0; p < 64; ++p) {
+    for (int u = 0; u < 4; ++u) bn[u] = in4[((size_t)p0 * 8 + 2 * u) * 32];
+    for (int p = p0; p < p1; ++p) {
         f32x4 b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1027,7 +1057,8 @@ __global__ __launch_bounds__(64) void build_stem_lut_k(const float* __restrict__
 
 __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ idx, const float* __restrict__ T, const float* __restrict__ bias,
                                                   float* __restrict__ out, float* __restrict__ out_mean, float* __restrict__ out_rstd,
-                                                  const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles)
+                                                  const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles,
+                                                  const int* __restrict__ od_start)
 {
     __shared__ uint8_t sidx[4][64 * 32];
     const int lane = threadIdx.x & 63;
@@ -1048,16 +1079,18 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
     for (int g = 0; g < 8; ++g) st[g].init();
     f32x4* out4 = (f32x4*)out + (size_t)tile * 64 * 16 * 32 + (size_t)h * 8 * 32 + j;
 
-    int4 e = steps[0];
-    int4 en = steps[1];
+    int od0, od1;
+    split_range<4>(od0, od1);
+    int si = gridDim.y > 1 ? od_start[od0] : 0;
+    int4 e = steps[si];
+    int4 en = steps[si + 1];
     f32x4 rn[8];
     {
         const int k = my[e.x * 32 + j];
 #pragma unroll
         for (int g = 0; g < 8; ++g) rn[g] = T4[((size_t)e.y * 256 + k) * 16 + g];
     }
-    int si = 0;
-    for (int po = 0; po < 64; ++po) {
+    for (int po = od0 * 16; po < od1 * 16; ++po) {
         f32x4 acc[8];
 #pragma unroll
         for (int g = 0; g < 8; ++g) acc[g] = (f32x4){0, 0, 0, 0};
@@ -1087,6 +1120,7 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
             st[g].add(v.w);
         }
     }
+    if (!out_mean) return;  // position-split launch: statistics by gn_stats_seq_k
     // GroupNorm(8,64): group = 8 channels = two 4-channel partials (low + high), both owned by this lane
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1094,6 +1128,94 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
         gn_finish(st[2 * k].s + st[2 * k + 1].s, st[2 * k].q + st[2 * k + 1].q, 1.0 / 512.0, m, r);
         out_mean[((size_t)tile * 8 + h * 4 + k) * 32 + j] = m;
         out_rstd[((size_t)tile * 8 + h * 4 + k) * 32 + j] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sequential statistics for the position-split path.  The fused statistics of the conv kernels are one fp64 chain per
+// (leaf, group) over positions ascending, channels ascending; a split launch cannot continue that chain across
+// workgroups, so it stores the activations only and these kernels walk them again in exactly that order (a wave
+// streams its slice at L2 speed; the chain itself is ~10 us for 512 positions).
+//   gn_stats_seq_k<C, NP, CPG>: mean / rstd of GroupNorm with CPG (2, 4 or 8) channels per group, [tile][C/CPG][32]
+//   csum_seq_k<C, NP>         : per-channel fp32 sums over the positions (ChannelAttention), [tile][C][32]
+//   ew_gn_relu_k<C, G>        : y = relu(GroupNorm_G(x)) elementwise (first-conv output, VQVAE_v2.py:236-237)
+// Wave w of a workgroup owns channel quads 2w, 2w+1 (lane half h -> quad 2w+h) of one leaf tile.
+// ------------------------------------------------------------------------------------------
+template <int C, int NP, int CPG>
+__global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd)
+{
+    static_assert(CPG == 2 || CPG == 4 || CPG == 8, "2/4: lane-local groups; 8: low quad + high quad of one wave");
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
+    const int tile = blockIdx.x;
+    const f32x4* in4 = (const f32x4*)x + (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
+    constexpr int NACC = CPG == 2 ? 2 : 1;
+    GnAcc st[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) st[k].init();
+#pragma unroll 8
+    for (int p = 0; p < NP; ++p) {
+        const f32x4 v = in4[(size_t)p * (C / 4) * 32];
+        st[0].add(v.x);
+        st[0].add(v.y);
+        st[CPG == 2 ? 1 : 0].add(v.z);
+        st[CPG == 2 ? 1 : 0].add(v.w);
+    }
+    constexpr int G = C / CPG;
+    if (CPG == 8) {  // group = this wave's two quads: low-quad partial + high-quad partial
+        float m, r;
+        gn_finish(st[0].s + shfl_xor32_f64(st[0].s), st[0].q + shfl_xor32_f64(st[0].q), 1.0 / (double)(8 * NP), m, r);
+        if ((lane >> 5) == 0) {
+            mean[((size_t)tile * G + (quad >> 1)) * 32 + j] = m;
+            rstd[((size_t)tile * G + (quad >> 1)) * 32 + j] = r;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        float m, r;
+        gn_finish(st[k].s, st[k].q, 1.0 / (double)(CPG * NP), m, r);
+        const int g = quad * (4 / CPG) + k;
+        mean[((size_t)tile * G + g) * 32 + j] = m;
+        rstd[((size_t)tile * G + g) * 32 + j] = r;
+    }
+}
+
+template <int C, int NP>
+__global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict__ x, float* __restrict__ csum)
+{
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
+    const int tile = blockIdx.x;
+    const f32x4* in4 = (const f32x4*)x + (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+    for (int p = 0; p < NP; ++p) s = s + in4[(size_t)p * (C / 4) * 32];
+    csum[((size_t)tile * C + 4 * quad + 0) * 32 + j] = s.x;
+    csum[((size_t)tile * C + 4 * quad + 1) * 32 + j] = s.y;
+    csum[((size_t)tile * C + 4 * quad + 2) * 32 + j] = s.z;
+    csum[((size_t)tile * C + 4 * quad + 3) * 32 + j] = s.w;
+}
+
+template <int C, int NP, int G>
+__global__ __launch_bounds__(256) void ew_gn_relu_k(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta)
+{
+    // one thread per float4 of the tile: index = (p*(C/4) + quad)*32 + j
+    const int tile = blockIdx.x;
+    constexpr int CPG = C / G;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < NP * (C / 4) * 32; i += gridDim.y * 256) {
+        const int j = i & 31, quad = (i >> 5) % (C / 4);
+        f32x4 v = ((const f32x4*)x)[(size_t)tile * NP * (C / 4) * 32 + i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * quad + k, g = c / CPG;
+            const float ia = rstd[((size_t)tile * G + g) * 32 + j] * gamma[c];
+            const float ib = __builtin_fmaf(-mean[((size_t)tile * G + g) * 32 + j], ia, beta[c]);
+            o[k] = fmaxf(__builtin_fmaf(o[k], ia, ib), 0.0f);
+        }
+        ((f32x4*)y)[(size_t)tile * NP * (C / 4) * 32 + i] = (f32x4){o[0], o[1], o[2], o[3]};
     }
 }
 

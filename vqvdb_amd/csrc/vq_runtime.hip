@@ -76,6 +76,7 @@ struct vqhip_codec {
     std::string err;
     hipStream_t stream = nullptr;
     int64_t chunk = 65536;
+    int split_tiles = 640;   // batches of up to this many 32-leaf tiles (20480 leaves) take the position-split path
 
     // device weights
     std::map<std::string, float*> dw;
@@ -341,6 +342,26 @@ int upload_i(vqhip_codec* c, const char* name, const std::vector<int>& v)
     return VQHIP_OK;
 }
 
+// schedule + index of the first step of every output od-slab (groups_per_od first-flagged steps each), for split launches
+int upload_steps(vqhip_codec* c, const std::string& name, const std::vector<int>& t, int groups_per_od)
+{
+    int rc = upload_i(c, name.c_str(), t);
+    if (rc) return rc;
+    std::vector<int> od;
+    int groups = 0;
+    for (size_t i = 0; i < t.size() / 4; ++i)
+        if (t[4 * i + 3] & 1) {
+            if (groups % groups_per_od == 0) od.push_back((int)i);
+            ++groups;
+        }
+    od.push_back((int)(t.size() / 4));
+    while (od.size() % 4) od.push_back(od.back());  // upload_i counts int4 entries
+    const int n_steps = c->nsteps[name];
+    rc = upload_i(c, (name + ".od").c_str(), od);
+    c->nsteps[name] = n_steps;
+    return rc;
+}
+
 int upload(vqhip_codec* c, const char* name, const std::vector<float>& v)
 {
     float* d = nullptr;
@@ -455,7 +476,7 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
     int rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
-    return upload_i(c, "steps.tail", steps);
+    return upload_steps(c, "steps.tail", steps, 1);
 }
 
 int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
@@ -508,11 +529,11 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("tr.wproj", frag32(epw->data, 128, 32, 1)) UP("tr.bproj", dfrag32(epb->data, 128))
     if ((rc = build_vq_fold(c, cb->data))) return rc;
 #undef UP
-    if ((rc = upload_i(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
-    if ((rc = upload_i(c, "steps.rowgroups8_4", steps_rowgroups8(4)))) return rc;
-    if ((rc = upload_i(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1)))) return rc;
-    if ((rc = upload_i(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1)))) return rc;
-    if ((rc = upload_i(c, "steps.rows8kd", steps_rows8_kd()))) return rc;
+    if ((rc = upload_steps(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1), 16))) return rc;     // one tap per step (streamed layers)
+    if ((rc = upload_steps(c, "steps.rowgroups8_4", steps_rowgroups8(4), 2))) return rc;
+    if ((rc = upload_steps(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1), 4))) return rc;
+    if ((rc = upload_steps(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1), 4))) return rc;
+    if ((rc = upload_steps(c, "steps.rows8kd", steps_rows8_kd(), 8))) return rc;
     {
         // decoder stem as a per-(tap, code) partial-sum table (stem_lut_k), built on the device once
         float* T = nullptr;
@@ -618,17 +639,105 @@ constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, res
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
 constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 
+constexpr auto k_dec_r64c1_s = conv_mfma32_k<64, 64, 64, 64, 2, true, 1, 1, 8, false, 0, false, 0>;
+constexpr auto k_dec_r64c2_s = conv_mfma32_k<64, 64, 64, 64, 2, true, 1, 1, 8, true, 0, false, 0>;
+constexpr auto k_dec_tail_s = conv_mfma32_k<64, 128, 64, 4, 2, true, 1, 2, 0, false, 0, false, 2>;
+// position-split (small-batch) variants: 2 tiles per workgroup, no fused statistics
+constexpr auto k_enc_down_s = conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 2, 0, 0, false, 0, false>;
+constexpr auto k_enc_r32c1_s = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 2, 1, 8, false, 0, false>;
+constexpr auto k_enc_r32c2_s = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 2, 1, 8, true, 0, false>;
+
 constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + projection A-fragments (144 KB)
 
 int init_kernel_attrs(vqhip_codec* c)
 {
     int rc;
+    if ((rc = set_lds(c, k_enc_down_s, LDS_ENC_DOWN))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c1_s, LDS_ENC_R32))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c2_s, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, k_enc_down, LDS_ENC_DOWN))) return rc;
     if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
     return VQHIP_OK;
+}
+
+void launch_latent_assign(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, float* d_latent, hipStream_t s, int split)
+{
+    auto& a = c->act;
+    auto& w = c->dw;
+    const int nt = (int)((n + 31) / 32);
+    // training forward: latent materialised, reference-faithful distance against the live codebook
+    L.run("train_codebook_frag", [&] { hipLaunchKernelGGL(codebook_frag_k, dim3(33), dim3(256), 0, s, w["cb"], w["tr.efrag"], w["tr.ee"]); });
+    LatentArgs A{};
+    A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+    A.wproj = w["tr.wproj"], A.bproj = w["tr.bproj"], A.efrag = w["tr.efrag"], A.ee_frag = w["tr.ee"];
+    A.idx = d_idx, A.z = d_latent, A.n_leaves = n, A.n_tiles = nt;
+    if (split <= 1 && nt >= 1024) L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<8>, dim3((nt + 7) / 8), dim3(512), LDS_LATENT, s, A); });
+    else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2, split > 1 ? split : 1), dim3(128), LDS_LATENT, s, A); });
+}
+
+// Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
+// od-slabs split over gridDim.y workgroups, activations are stored, and the GroupNorm / channel-sum statistics are
+// recomputed by sequential kernels in the contract's order.  Same results bit for bit, ~5x lower latency.
+int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, hipStream_t s, float* d_latent)
+{
+    const int nt = (int)((n + 31) / 32);
+    auto& a = c->act;
+    auto& w = c->dw;
+    auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".od"]); };
+    const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
+    {
+        ConvArgs A{};
+        A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        A.n_steps = c->nsteps["steps.rows8kd"], A.od_start = od("steps.rows8kd");
+        L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, 8), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        L.run("enc_stats_y1", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 4>), dim3(nt), dim3(128), 0, s, a["e_y1"], a["st_a.mean"], a["st_a.rstd"]); });
+        L.run("enc_gn_relu_a1", [&] {
+            hipLaunchKernelGGL((ew_gn_relu_k<16, 512, 4>), dim3(nt, 16), dim3(256), 0, s, a["e_y1"], a["e_a1"], a["st_a.mean"], a["st_a.rstd"], w["eg0.w"], w["eg0.b"]);
+        });
+        L.run("enc_stats_a1", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 2>), dim3(nt), dim3(128), 0, s, a["e_a1"], a["st_b.mean"], a["st_b.rstd"]); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
+        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
+        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.od_start = od("steps.rowgroups8_4");
+        L.run("enc_res16_conv1_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, false>), dim3((2 * nt + 3) / 4, 8), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 2>), dim3(nt), dim3(128), 0, s, a["e_y4"], a["st_a.mean"], a["st_a.rstd"]); });
+        A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
+        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
+        L.run("enc_res16_conv2_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4, 8), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"], A.n_tiles = nt;
+        A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.od_start = od("steps.rows_k4s2_8");
+        L.run("enc_down_s", [&] { hipLaunchKernelGGL(k_enc_down_s, dim3(g2, 4), dim3(128), LDS_ENC_DOWN, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
+        L.run("enc_stats_x7", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_x7"], a["st_b.mean"], a["st_b.rstd"]); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
+        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
+        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.od_start = od("steps.rows_k3_4");
+        L.run("enc_res32_conv1_s", [&] { hipLaunchKernelGGL(k_enc_r32c1_s, dim3(g2, 4), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_stats_y9", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_y9"], a["st_a.mean"], a["st_a.rstd"]); });
+        A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
+        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
+        L.run("enc_res32_conv2_s", [&] { hipLaunchKernelGGL(k_enc_r32c2_s, dim3(g2, 4), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"]); });
+    }
+    if (d_latent) {
+        launch_latent_assign(c, L, n, d_idx, d_latent, s, 8);
+        return L.rc;
+    }
+    VqArgs A{};
+    A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+    A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
+    L.run("enc_vq_s", [&] { hipLaunchKernelGGL(vq_folded_k<2>, dim3(g2, 8), dim3(128), 0, s, A); });
+    return L.rc;
 }
 
 int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, hipStream_t s, float* d_latent = nullptr)
@@ -642,6 +751,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
     L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt), dim3(256), 0, s, d_leaves, a["xt"], n); });
+    if (nt <= c->split_tiles) return encode_chunk_split(c, L, n, d_idx, s, d_latent);
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
@@ -691,14 +801,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     if (d_latent) {
-        // training forward: latent materialised, reference-faithful distance against the live codebook
-        L.run("train_codebook_frag", [&] { hipLaunchKernelGGL(codebook_frag_k, dim3(33), dim3(256), 0, s, w["cb"], w["tr.efrag"], w["tr.ee"]); });
-        LatentArgs A{};
-        A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
-        A.wproj = w["tr.wproj"], A.bproj = w["tr.bproj"], A.efrag = w["tr.efrag"], A.ee_frag = w["tr.ee"];
-        A.idx = d_idx, A.z = d_latent, A.n_leaves = n, A.n_tiles = nt;
-        if (nt >= 1024) L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<8>, dim3(g8), dim3(512), LDS_LATENT, s, A); });
-        else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2), dim3(128), LDS_LATENT, s, A); });
+        launch_latent_assign(c, L, n, d_idx, d_latent, s, 1);
         return L.rc;
     }
     {
@@ -706,6 +809,45 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
         A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
         L.run("enc_vq", [&] { hipLaunchKernelGGL(vq_folded_k<8>, dim3(g8), dim3(512), 0, s, A); });
+    }
+    return L.rc;
+}
+
+// position-split decode for small batches (see encode_chunk_split)
+int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_t n, float* d_out, hipStream_t s)
+{
+    const int nt = (int)((n + 31) / 32);
+    auto& a = c->act;
+    auto& w = c->dw;
+    auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".od"]); };
+    const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
+    L.run("dec_stem_s", [&] {
+        hipLaunchKernelGGL(stem_lut_k, dim3(g4, 4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
+                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"));
+    });
+    L.run("dec_stats_ystem", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_ystem"], a["st_a.mean"], a["st_a.rstd"]); });
+    L.run("dec_gn_relu_d2", [&] {
+        hipLaunchKernelGGL((ew_gn_relu_k<64, 64, 8>), dim3(nt, 8), dim3(256), 0, s, a["d_ystem"], a["d_d2"], a["st_a.mean"], a["st_a.rstd"], w["dg0.w"], w["dg0.b"]);
+    });
+    L.run("dec_stats_d2", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_d2"], a["st_b.mean"], a["st_b.rstd"]); });
+    {
+        ConvArgs A{};
+        A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
+        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"], A.n_tiles = nt;
+        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27, A.od_start = od("steps.k3s1_4");
+        L.run("dec_res64_conv1_s", [&] { hipLaunchKernelGGL(k_dec_r64c1_s, dim3(g2, 4), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        L.run("dec_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_y4"], a["st_a.mean"], a["st_a.rstd"]); });
+        A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w"], A.bias_frag = w["r64c2.b"], A.skip = a["d_d2"];
+        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
+        L.run("dec_res64_conv2_s", [&] { hipLaunchKernelGGL(k_dec_r64c2_s, dim3(g2, 4), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"]); });
+    }
+    {
+        ConvArgs A{};
+        A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
+        A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
+        A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.od_start = od("steps.tail");
+        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(k_dec_tail_s, dim3(g2, 4), dim3(128), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
     }
     return L.rc;
 }
@@ -720,9 +862,10 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
+    if (nt <= 2 * c->split_tiles) return decode_chunk_split(c, L, d_idx, n, d_out, s);  // the decoder's crossover is about twice the encoder's
     L.run("dec_stem", [&] {
         hipLaunchKernelGGL(stem_lut_k, dim3(g4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
-                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt);
+                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
     });
     {
         ConvArgs A{};
@@ -1075,6 +1218,14 @@ int vqhip_set_chunk_leaves(vqhip_codec* c, int64_t chunk)
     if (!c) return VQHIP_ERR_INVALID;
     if (chunk < 32 || chunk > (1 << 22)) return fail(c, VQHIP_ERR_INVALID, "chunk_leaves must be in [32, 4194304]");
     c->chunk = (chunk + 31) / 32 * 32;
+    return VQHIP_OK;
+}
+
+int vqhip_set_small_batch_tiles(vqhip_codec* c, int tiles)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (tiles < 0) return fail(c, VQHIP_ERR_INVALID, "small_batch_tiles must be >= 0");
+    c->split_tiles = tiles;
     return VQHIP_OK;
 }
 

@@ -83,7 +83,9 @@ __global__ __launch_bounds__(NW * 64, 2) void latent_assign_k(LatentArgs A)
     const f32x4* ee4 = (const f32x4*)A.ee_frag;
     const int64_t leaf = (int64_t)tile * 32 + j;
     const bool live = leaf < A.n_leaves;
-    for (int p = 0; p < 64; ++p) {
+    int p0 = 0, p1 = 64;
+    if (gridDim.y > 1) p0 = (int)(blockIdx.y * 64 / gridDim.y), p1 = (int)((blockIdx.y + 1) * 64 / gridDim.y);
+    for (int p = p0; p < p1; ++p) {
         f32x16 z[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
