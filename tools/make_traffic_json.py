@@ -10,15 +10,15 @@ import sys
 
 LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the library's profiler)
     (r"conv_first_k<0>", "enc_conv_first_stats"), (r"conv_first_k<1>", "enc_conv_first_gn"),
-    (r"conv8_c16_k<false, true>", "enc_res16_conv1"), (r"conv8_c16_k<true, false>", "enc_res16_conv2"),
-    (r"conv_mfma32_k<16, 32, 512", "enc_down"),
-    (r"conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, false", "enc_res32_conv1"),
-    (r"conv_mfma32_k<32, 32, 64, 64, 8, false, 3, 1, 8, true", "enc_res32_conv2"),
-    (r"proj_vq_k", "enc_proj_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
+    (r"conv8_c16_k<4, false, true>", "enc_res16_conv1"), (r"conv8_c16_k<4, true, false>", "enc_res16_conv2"),
+    (r"conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 8,", "enc_down"),
+    (r"conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, false", "enc_res32_conv1"),
+    (r"conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, true", "enc_res32_conv2"),
+    (r"vq_folded_k<8>", "enc_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
     (r"gn_relu_stats_k<64", "dec_gn_relu_stats"),
     (r"conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false", "dec_res64_conv1"),
     (r"conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true", "dec_res64_conv2"),
-    (r"conv_mfma32_k<64, 128, 64, 4,", "dec_tail"),
+    (r"conv_mfma32_k<64, 128, 64, 4, 8,", "dec_tail"),
 ]
 
 

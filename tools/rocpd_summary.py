@@ -34,8 +34,10 @@ def main():
     ap.add_argument("--write")
     a = ap.parse_args()
     db = sqlite3.connect(a.kt)
+    # one row per (kernel, launch geometry): the same kernel is launched at 65536 leaves by the throughput legs and at small
+    # batches (or with gridDim.y > 1, the position-split path) by the training leg; averaging across them would be meaningless
     rows = list(db.execute("select name, count(*), avg(duration), sum(duration), max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(scratch_size),"
-                           " max(workgroup_x), max(grid_x) from kernels group by name order by sum(duration) desc"))
+                           " max(workgroup_x), grid_x * grid_y from kernels group by name, grid_x, grid_y order by sum(duration) desc"))
     f = pmc(a.fetch, "FETCH_SIZE") if a.fetch else {}
     w = pmc(a.write, "WRITE_SIZE") if a.write else {}
     tot = sum(r[3] for r in rows)
