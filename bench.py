@@ -192,6 +192,21 @@ def main():
     enc_lps = world * args.steps * BATCH / t_enc
     dec_lps = world * args.steps * BATCH / t_dec
 
+    # Small-batch latency (position-split kernels): what the SOP's per-batch calls see (default 64, max 1024 encode / 8192
+    # decode leaves, SOP_VQVDB_Encoder.cpp:33-38).  Device-resident, rank 0 only.
+    small = None
+    if rank == 0:
+        small = {"note": "ms per call on the device at SOP-sized batches (position-split path); not the headline value"}
+        for nsm in (64, 1024, 8192):
+            for _ in range(3):
+                codec.encode_device(leaves[0].data_ptr(), nsm, idx[0].data_ptr(), stream)
+                codec.decode_device(idx[0].data_ptr(), nsm, rec.data_ptr(), stream)
+            t_e = timed(lambda s: codec.encode_device(leaves[0].data_ptr(), nsm, idx[0].data_ptr(), stream), 10, False, device)
+            t_d = timed(lambda s: codec.decode_device(idx[0].data_ptr(), nsm, rec.data_ptr(), stream), 10, False, device)
+            small[f"leaves_{nsm}"] = {"encode_ms": round(t_e / 10 * 1e3, 4), "decode_ms": round(t_d / 10 * 1e3, 4),
+                                      "encode_leaves_per_s": round(nsm * 10 / t_e, 1), "decode_leaves_per_s": round(nsm * 10 / t_d, 1)}
+        enc(0)   # idx[0] back to the full batch's indices for the parity spot check below
+
     # Codebook (EMA) training steps, the quantizer part of BASELINE configs[4]: per-rank batches of 2048 leaves (the
     # reference's BATCH_SIZE, python/training.py:49) and of 65536 leaves; statistics all-reduced over RCCL when N > 1.
     train = None
@@ -263,6 +278,7 @@ def main():
             "parity_sample": parity,
             "host_path": host,
             "codebook_training": train,
+            "small_batch": small,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:

@@ -169,6 +169,11 @@ int vqhip_train_begin(vqhip_codec* codec, const float* cluster_size, const float
  * indices_dev ([n][64] uint8) and latent_dev ([n*64][128] float, the reference's `flat` rows) may be NULL. */
 int vqhip_train_vq_stats_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, float* stats_dev, uint8_t* indices_dev,
                                 float* latent_dev, void* hip_stream);
+/* Validation forward (python/training.py:183-199; VQVAE.forward in eval mode, VQVAE_v2.py:344-348): the statistics of
+ * vqhip_train_vq_stats_device without any update, plus the reconstruction through the decoder and
+ * recon_sums_dev[3] = { sum (recon-x)^2, sum |recon-x|, voxels }.  recon_dev ([n][512]) may be NULL. */
+int vqhip_train_eval_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, float* stats_dev, float* recon_sums_dev,
+                            float* recon_dev, void* hip_stream);
 /* EMA update from the (all-reduced) statistics: cluster_size = decay*cluster_size + (1-decay)*encodings_sum, embed_avg likewise
  * with dw, embedding = embed_avg / max(cluster_size, eps)  (VQVAE_v2.py:135-144; reference defaults decay 0.95, eps 1e-4). */
 int vqhip_train_vq_update_device(vqhip_codec* codec, const float* stats_dev, float decay, float eps, void* hip_stream);

@@ -138,3 +138,18 @@ def test_two_rank_allreduce_of_codebook_statistics_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_counts and err < 1e-6 and same and n_dead > 0
+
+
+def test_oracle_validation_forward_matches_reference(oracle, weights, gt):
+    """training.py:183-199 in eval mode: losses of decode(assign(encoder(x))) against the imported reference's forward."""
+    x = synth.make_leaves(64, seed=4100)
+    E = weights["quantizer.embedding"]
+    z = oracle.latent(x, threads=8)
+    idx = oracle.vq_assign(z, E, threads=8)
+    m = metrics_from_stats(oracle.vq_stats(z, idx, E), 0.25)
+    rec = oracle.decode(idx.reshape(64, 64), threads=8)
+    d = rec.astype(np.float64) - x
+    assert abs((d * d).mean() - float(gt["eval_recon_mse"])) < 1e-5 * float(gt["eval_recon_mse"])
+    assert abs(np.abs(d).mean() - float(gt["eval_recon_l1"])) < 1e-5 * float(gt["eval_recon_l1"])
+    assert abs(m["vq_loss"] - float(gt["eval_vq_loss"])) < 1e-4 * float(gt["eval_vq_loss"])
+    assert abs(m["perplexity"] - float(gt["eval_ppl"])) < 1e-4 * float(gt["eval_ppl"])

@@ -115,3 +115,21 @@ def test_training_entry_points_fail_loudly(weights):
     with pytest.raises(RuntimeError, match="decay"):
         c.train_vq_update_device(stats.data_ptr(), 1.5, 1e-4)
     c.close()
+
+
+def test_validation_forward_matches_reference(tcodec, gt):  # noqa: F811
+    tr = CodebookTrainer(tcodec)
+    m = tr.evaluate(torch.from_numpy(synth.make_leaves(64, seed=4100)).cuda())
+    assert abs(m["recon_mse"] - float(gt["eval_recon_mse"])) < 1e-5 * float(gt["eval_recon_mse"])
+    assert abs(m["recon_l1"] - float(gt["eval_recon_l1"])) < 1e-5 * float(gt["eval_recon_l1"])
+    assert abs(m["vq_loss"] - float(gt["eval_vq_loss"])) < 1e-4 * float(gt["eval_vq_loss"])
+    assert abs(m["perplexity"] - float(gt["eval_ppl"])) < 1e-4 * float(gt["eval_ppl"])
+    assert abs(m["recon_error"] - (0.8 * m["recon_mse"] + 0.2 * m["recon_l1"])) < 1e-12
+    # evaluation leaves the state untouched and works after training steps too (stale tables refreshed on demand)
+    before = tcodec.train_get_state()
+    tr.step(torch.from_numpy(synth.make_leaves(128, seed=5)).cuda())
+    m2 = tr.evaluate(torch.from_numpy(synth.make_leaves(64, seed=4100)).cuda())
+    after = tcodec.train_get_state()
+    assert not np.array_equal(before["embedding"], after["embedding"]) and m2["vq_loss"] != m["vq_loss"]
+    m3 = tr.evaluate(torch.from_numpy(synth.make_leaves(64, seed=4100)).cuda())
+    assert m3 == m2 and all(np.array_equal(after[k], tcodec.train_get_state()[k]) for k in after)

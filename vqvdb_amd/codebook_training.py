@@ -110,6 +110,28 @@ class CodebookTrainer:
         cur.wait_stream(self.stream)
         return out
 
+    def evaluate(self, leaves: torch.Tensor, mse_weight: float = 0.8, l1_weight: float = 0.2) -> dict:
+        """Validation forward on this rank's batch (training.py:183-199): reconstruction MSE / L1 (and the reference's
+        0.8 / 0.2 mix, :151-155), vq_loss and perplexity over the GLOBAL batch; nothing is updated."""
+        leaves = leaves.contiguous()
+        if leaves.dtype != torch.float32 or leaves.numel() % 512:
+            raise ValueError("leaves must be float32 with 512 values per leaf")
+        n = leaves.numel() // 512
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            buf = torch.zeros(STATS_FLOATS + 3, dtype=torch.float32, device=self.device)
+            self.codec.train_eval_device(leaves.data_ptr(), n, buf.data_ptr(), buf[STATS_FLOATS:].data_ptr(), stream=self.stream.cuda_stream)
+            allreduce_stats(buf, self.group)
+            host = buf.cpu().numpy().astype(np.float64)
+        leaves.record_stream(self.stream)
+        cur.wait_stream(self.stream)
+        out = metrics_from_stats(host[:STATS_FLOATS], self.commitment_cost)
+        sq, ab, elems = host[STATS_FLOATS:]
+        out.update(recon_mse=float(sq / elems), recon_l1=float(ab / elems))
+        out["recon_error"] = mse_weight * out["recon_mse"] + l1_weight * out["recon_l1"]
+        return out
+
     def reset_dead_codes(self, flat_z: Optional[torch.Tensor] = None, threshold: float = 1.0, generator=None) -> int:
         flat_z = self.latent if flat_z is None else flat_z
         if flat_z is None:

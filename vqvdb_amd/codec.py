@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "vqhip_multi_create", "vqhip_multi_destroy", "vqhip_multi_last_error", "vqhip_multi_encode", "vqhip_multi_decode",
     "vqhip_decompress_file", "vqhip_compress_file", "vqhip_reserve",
     "vqhip_train_begin", "vqhip_train_vq_stats_device", "vqhip_train_vq_update_device", "vqhip_train_get_state", "vqhip_train_set_state",
-    "vqhip_train_commit", "vqhip_set_small_batch_tiles",
+    "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -146,6 +146,7 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_train_begin.argtypes = [vp, vp, vp]
     lib.vqhip_train_vq_stats_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.vqhip_train_vq_update_device.argtypes = [vp, vp, ctypes.c_float, ctypes.c_float, vp]
+    lib.vqhip_train_eval_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.vqhip_train_get_state.argtypes = [vp, vp, vp, vp]
     lib.vqhip_train_set_state.argtypes = [vp, vp, vp, vp]
     lib.vqhip_train_commit.argtypes = [vp]
@@ -314,6 +315,9 @@ class HipCodec:
 
     def train_vq_stats_device(self, leaves_ptr: int, n: int, stats_ptr: int, idx_ptr: int = 0, latent_ptr: int = 0, stream: int = 0):
         self._check(self._lib.vqhip_train_vq_stats_device(self._h, leaves_ptr, n, stats_ptr, idx_ptr or None, latent_ptr or None, stream or None))
+
+    def train_eval_device(self, leaves_ptr: int, n: int, stats_ptr: int, recon_sums_ptr: int, recon_ptr: int = 0, stream: int = 0):
+        self._check(self._lib.vqhip_train_eval_device(self._h, leaves_ptr, n, stats_ptr, recon_sums_ptr, recon_ptr or None, stream or None))
 
     def train_vq_update_device(self, stats_ptr: int, decay: float = 0.95, eps: float = 1e-4, stream: int = 0):
         self._check(self._lib.vqhip_train_vq_update_device(self._h, stats_ptr, decay, eps, stream or None))

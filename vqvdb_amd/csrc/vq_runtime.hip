@@ -115,6 +115,9 @@ struct vqhip_codec {
     int64_t tr_leaves = 0;
     char* tr_part = nullptr;   // per-(code, row segment) partial statistics
     size_t tr_part_bytes = 0;
+    float* tr_recon = nullptr;  // reconstruction scratch of vqhip_train_eval_device
+    int64_t tr_recon_leaves = 0;
+    double* tr_loss_part = nullptr;
 };
 
 namespace {
@@ -974,7 +977,7 @@ void host_parallel_copy(void* dst, const void* src, size_t bytes)
 int refresh_tables(vqhip_codec* c)
 {
     std::vector<float> E(256 * 128);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());  // the codebook may have been updated on a caller's stream
     HIPCHK(c, hipMemcpy(E.data(), c->dw["cb"], E.size() * sizeof(float), hipMemcpyDeviceToHost));
     int rc = build_vq_fold(c, E.data());
     if (rc) return rc;
@@ -1187,6 +1190,8 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->tr_z) hipFree(c->tr_z);
     if (c->tr_idx) hipFree(c->tr_idx);
     if (c->tr_part) hipFree(c->tr_part);
+    if (c->tr_recon) hipFree(c->tr_recon);
+    if (c->tr_loss_part) hipFree(c->tr_loss_part);
     for (int i = 0; i < 2; ++i) {
         if (c->dev_leaves[i]) hipFree(c->dev_leaves[i]);
         if (c->dev_idx[i]) hipFree(c->dev_idx[i]);
@@ -1573,6 +1578,39 @@ int vqhip_train_vq_stats_device(vqhip_codec* c, const float* d_leaves, int64_t n
         hipLaunchKernelGGL(vq_ema_partials_k, dim3(256, (n_seg + 15) / 16), dim3(1024), 0, s, z, idx, c->dw["cb"], rows, n_seg, part, sqpart, cntpart);
     });
     L.run("train_vq_ema_reduce", [&] { hipLaunchKernelGGL(vq_ema_reduce_k, dim3(256), dim3(128), 0, s, part, sqpart, cntpart, rows, n_seg, d_stats); });
+    return L.rc;
+}
+
+int vqhip_train_eval_device(vqhip_codec* c, const float* d_leaves, int64_t n, float* d_stats, float* d_recon_sums, float* d_recon, void* stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!c->training) return fail(c, VQHIP_ERR_INVALID, "train_eval: call vqhip_train_begin first");
+    if (!d_leaves || !d_stats || !d_recon_sums || n < 1) return fail(c, VQHIP_ERR_INVALID, "train_eval: null pointer or n_leaves < 1");
+    if (n > c->chunk) return fail(c, VQHIP_ERR_INVALID, "train_eval: a batch may not exceed the chunk size (" + std::to_string(c->chunk) + " leaves)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // forward in eval mode (VQVAE.forward, VQVAE_v2.py:344-348): assignment + statistics exactly as in training, no update
+    int rc = vqhip_train_vq_stats_device(c, d_leaves, n, d_stats, nullptr, nullptr, s);
+    if (rc) return rc;
+    if ((rc = ensure_tables(c))) return rc;  // the decoder's stem table follows the live codebook
+    float* recon = d_recon;
+    if (!recon) {
+        if (c->tr_recon_leaves < n) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->tr_recon) hipFree(c->tr_recon);
+            c->tr_recon = nullptr, c->tr_recon_leaves = 0;
+            HIPCHK(c, hipMalloc(&c->tr_recon, (size_t)n * 512 * sizeof(float)));
+            c->tr_recon_leaves = n;
+        }
+        recon = c->tr_recon;
+    }
+    if (!c->tr_loss_part) HIPCHK(c, hipMalloc(&c->tr_loss_part, (size_t)RL_BLOCKS * 2 * sizeof(double)));
+    if ((rc = decode_chunk(c, c->tr_idx, n, recon, s))) return rc;
+    Launcher L{c, s, n};
+    L.run("train_recon_loss", [&] {
+        hipLaunchKernelGGL(recon_loss_partials_k, dim3(RL_BLOCKS), dim3(256), 0, s, d_leaves, recon, n * 512, c->tr_loss_part);
+        hipLaunchKernelGGL(recon_loss_reduce_k, dim3(1), dim3(1), 0, s, c->tr_loss_part, n * 512, d_recon_sums);
+    });
     return L.rc;
 }
 

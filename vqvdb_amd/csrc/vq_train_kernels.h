@@ -266,3 +266,44 @@ __global__ __launch_bounds__(128) void vq_ema_update_k(const float* __restrict__
     __syncthreads();  // every thread has read cluster_size[k]
     if (c == 0) cluster_size[k] = cs;
 }
+
+// Validation losses of the reference loop (python/training.py:183-199: F.mse_loss / F.l1_loss of the reconstruction):
+// sums of (y-x)^2 and |y-x| over all voxels.  Fixed launch geometry (RL_BLOCKS x 256 threads, grid-stride), fp64 partials,
+// block tree in LDS, then one thread adds the block partials in order -> deterministic.
+#define RL_BLOCKS 1024
+__global__ __launch_bounds__(256) void recon_loss_partials_k(const float* __restrict__ x, const float* __restrict__ y, int64_t n_elems,
+                                                              double* __restrict__ part /*[RL_BLOCKS][2]*/)
+{
+    __shared__ double s2[256], s1[256];
+    double a2 = 0.0, a1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)RL_BLOCKS * 256) {
+        const double d = (double)y[i] - (double)x[i];
+        a2 = fma(d, d, a2);
+        a1 += d < 0.0 ? -d : d;
+    }
+    s2[threadIdx.x] = a2;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s2[threadIdx.x] += s2[threadIdx.x + w];
+            s1[threadIdx.x] += s1[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = s2[0];
+        part[2 * blockIdx.x + 1] = s1[0];
+    }
+}
+__global__ void recon_loss_reduce_k(const double* __restrict__ part, int64_t n_elems, float* __restrict__ out /*[3]: sum sq, sum abs, elems*/)
+{
+    double a2 = 0.0, a1 = 0.0;
+    for (int b = 0; b < RL_BLOCKS; ++b) {
+        a2 += part[2 * b];
+        a1 += part[2 * b + 1];
+    }
+    out[0] = (float)a2;
+    out[1] = (float)a1;
+    out[2] = (float)n_elems;
+}
