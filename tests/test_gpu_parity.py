@@ -157,7 +157,8 @@ def test_cpp_adapter_orchestrator_roundtrip(codec, pack, tmp_path):
     """C++ host side (HipBackend : IVQVAECodec via IVQVAECodec::create, orchestrator-style batching,
     .vqvdb framing) gives the same bytes as the C-ABI path, for SOP-default and large batches."""
     import subprocess
-    from vqvdb_amd.build import HARNESS
+    from vqvdb_amd.build import build_harness
+    HARNESS = build_harness()
     leaves = synth.make_leaves(1000, seed=21)
     (tmp_path / "m.vqw").write_bytes(pack)
     leaves.tofile(tmp_path / "in.f32")
@@ -236,7 +237,8 @@ def test_cpp_harness_stream_modes_match_orchestrator_modes(codec, pack, tmp_path
     """leaf_harness compress_stream / decompress_stream (C ABI whole-file entry points, hash-map leaf store standing in
     for tree.touchLeaf) write the same files as the orchestrator-shaped compress / decompress modes."""
     import subprocess
-    from vqvdb_amd.build import HARNESS
+    from vqvdb_amd.build import build_harness
+    HARNESS = build_harness()
     leaves = synth.make_leaves(5000, seed=33)
     (tmp_path / "m.vqw").write_bytes(pack)
     leaves.tofile(tmp_path / "in.f32")
