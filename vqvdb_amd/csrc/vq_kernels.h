@@ -31,21 +31,21 @@ struct ConvArgs {
     int n_taps;
     int64_t n_leaves;        // OUTMODE 2 only: leaves that really exist (the last tile may be padded)
     int n_tiles;
-    // Position-split launches (small batches: too few leaf tiles to fill 1024 SIMDs): gridDim.y > 1 cuts the output
-    // od-slabs into gridDim.y ranges; od_start[od] = index of the first schedule step of slab od.  Kernels launched
-    // this way are instantiated without fused statistics (gn_stats_seq_k / csum_seq_k recompute them in the
-    // contract's sequential order from the stored output).
-    const int* od_start;
+    // Position-split launches (small batches: too few leaf tiles to fill 1024 SIMDs): gridDim.y > 1 cuts the kernel's
+    // output groups (the units its outer loop walks: rows, row groups or positions) into gridDim.y ranges;
+    // grp_start[g] = index of the first schedule step of group g.  Kernels launched this way are instantiated without
+    // fused statistics (gn_stats_seq_k / csum_seq_k recompute them in the contract's sequential order from the stored output).
+    const int* grp_start;
 };
 
-// slab range [od0, od1) of this workgroup for an output with NOD slabs
-template <int NOD>
-__device__ __forceinline__ void split_range(int& od0, int& od1)
+// group range [g0, g1) of this workgroup for a kernel whose outer loop walks NG output groups
+template <int NG>
+__device__ __forceinline__ void split_range(int& g0, int& g1)
 {
-    od0 = 0, od1 = NOD;
+    g0 = 0, g1 = NG;
     if (gridDim.y > 1) {
-        od0 = (int)(blockIdx.y * NOD / gridDim.y);
-        od1 = (int)((blockIdx.y + 1) * NOD / gridDim.y);
+        g0 = (int)(blockIdx.y * NG / gridDim.y);
+        g1 = (int)((blockIdx.y + 1) * NG / gridDim.y);
     }
 }
 
@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
         for (int k = 0; k < (MODE == 1 ? 2 : 1); ++k) st[sb][k].init();
 
     const int NS = A.n_steps;
-    int od0, od1;
-    split_range<8>(od0, od1);
-    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int g0, g1;
+    split_range<64>(g0, g1);
+    int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1];
     // step entry: x = centre input row base (id*8+oh)*8, y = kd, w bits 8..10 = valid kh mask
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
             xn[kh][ow][1] = x[rb + off[ow] + 16];
         }
     }
-    for (int row = od0 * 8; row < od1 * 8; ++row) {
+    for (int row = g0; row < g1; ++row) {
         f32x4 acc[8][2];
 #pragma unroll
         for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
@@ -370,15 +370,15 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
     st[0].init();
     st[1].init();
     const int NS = A.n_steps;
-    int od0, od1;
-    split_range<8>(od0, od1);
-    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int g0, g1;
+    split_range<64 / NR>(g0, g1);
+    int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1];
     f32x4 xr[8];
 #pragma unroll
     for (int iw = 0; iw < 8; ++iw) xr[iw] = in4[((size_t)(e.x + iw) * 4) * 32];
-    for (int grp = od0 * (8 / NR); grp < od1 * (8 / NR); ++grp) {  // 8 od x (8/NR) row groups
+    for (int grp = g0; grp < g1; ++grp) {  // 8 od x (8/NR) row groups
         f32x4 acc[NR][8];
 #pragma unroll
         for (int rw = 0; rw < NR; ++rw)
@@ -549,10 +549,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     const int NS = A.n_steps;
 
     // ---- pipeline prologue: table entries two ahead, operands one step ahead ----
-    constexpr int PPO = NPO >= 4 ? NPO / 4 : 1;  // output positions per od-slab (4 slabs)
-    int od0, od1;
-    split_range<4>(od0, od1);
-    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int g0, g1;
+    split_range<NPO>(g0, g1);
+    int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
     f32x4 bn[KWG][NU];
@@ -569,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
             glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAP + piece * 64);
         }
     }
-    for (int po = od0 * PPO; po < od1 * PPO; ++po) {
+    for (int po = g0; po < g1; ++po) {
         f32x16 acc[NMT];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
@@ -777,9 +776,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_rows32_k(ConvArgs A, const in
     const f32x4* bf4 = (const f32x4*)A.bias_frag;
     const int NS = A.n_steps;
 
-    int od0, od1;
-    split_range<SO>(od0, od1);
-    int si = gridDim.y > 1 ? A.od_start[od0] : 0;
+    int g0, g1;
+    split_range<SO * SO>(g0, g1);
+    int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
     f32x4 xr[SI][NU];  // input row of the current step; re-loaded position by position for the next step
@@ -787,7 +786,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_rows32_k(ConvArgs A, const in
     for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
         for (int u = 0; u < NU; ++u) xr[iw][u] = in4[(size_t)(e.x + iw) * (CIN / 4) * 32 + u * 64];
-    for (int row = od0 * SO; row < od1 * SO; ++row) {
+    for (int row = g0; row < g1; ++row) {
         f32x16 acc[SO][NMT];
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow)
@@ -1058,7 +1057,7 @@ __global__ __launch_bounds__(64) void build_stem_lut_k(const float* __restrict__
 __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ idx, const float* __restrict__ T, const float* __restrict__ bias,
                                                   float* __restrict__ out, float* __restrict__ out_mean, float* __restrict__ out_rstd,
                                                   const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles,
-                                                  const int* __restrict__ od_start)
+                                                  const int* __restrict__ grp_start)
 {
     __shared__ uint8_t sidx[4][64 * 32];
     const int lane = threadIdx.x & 63;
@@ -1079,9 +1078,9 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
     for (int g = 0; g < 8; ++g) st[g].init();
     f32x4* out4 = (f32x4*)out + (size_t)tile * 64 * 16 * 32 + (size_t)h * 8 * 32 + j;
 
-    int od0, od1;
-    split_range<4>(od0, od1);
-    int si = gridDim.y > 1 ? od_start[od0] : 0;
+    int g0, g1;
+    split_range<64>(g0, g1);
+    int si = gridDim.y > 1 ? grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1];
     f32x4 rn[8];
@@ -1090,7 +1089,7 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
 #pragma unroll
         for (int g = 0; g < 8; ++g) rn[g] = T4[((size_t)e.y * 256 + k) * 16 + g];
     }
-    for (int po = od0 * 16; po < od1 * 16; ++po) {
+    for (int po = g0; po < g1; ++po) {
         f32x4 acc[8];
 #pragma unroll
         for (int g = 0; g < 8; ++g) acc[g] = (f32x4){0, 0, 0, 0};

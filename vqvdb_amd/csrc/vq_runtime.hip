@@ -345,22 +345,18 @@ int upload_i(vqhip_codec* c, const char* name, const std::vector<int>& v)
     return VQHIP_OK;
 }
 
-// schedule + index of the first step of every output od-slab (groups_per_od first-flagged steps each), for split launches
-int upload_steps(vqhip_codec* c, const std::string& name, const std::vector<int>& t, int groups_per_od)
+// schedule + index of the first step of every output group (first-flagged steps), for position-split launches
+int upload_steps(vqhip_codec* c, const std::string& name, const std::vector<int>& t)
 {
     int rc = upload_i(c, name.c_str(), t);
     if (rc) return rc;
-    std::vector<int> od;
-    int groups = 0;
+    std::vector<int> g;
     for (size_t i = 0; i < t.size() / 4; ++i)
-        if (t[4 * i + 3] & 1) {
-            if (groups % groups_per_od == 0) od.push_back((int)i);
-            ++groups;
-        }
-    od.push_back((int)(t.size() / 4));
-    while (od.size() % 4) od.push_back(od.back());  // upload_i counts int4 entries
+        if (t[4 * i + 3] & 1) g.push_back((int)i);
+    g.push_back((int)(t.size() / 4));
+    while (g.size() % 4) g.push_back(g.back());  // upload_i counts int4 entries
     const int n_steps = c->nsteps[name];
-    rc = upload_i(c, (name + ".od").c_str(), od);
+    rc = upload_i(c, (name + ".grp").c_str(), g);
     c->nsteps[name] = n_steps;
     return rc;
 }
@@ -479,7 +475,7 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
     int rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
-    return upload_steps(c, "steps.tail", steps, 1);
+    return upload_steps(c, "steps.tail", steps);
 }
 
 int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
@@ -532,11 +528,11 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("tr.wproj", frag32(epw->data, 128, 32, 1)) UP("tr.bproj", dfrag32(epb->data, 128))
     if ((rc = build_vq_fold(c, cb->data))) return rc;
 #undef UP
-    if ((rc = upload_steps(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1), 16))) return rc;     // one tap per step (streamed layers)
-    if ((rc = upload_steps(c, "steps.rowgroups8_4", steps_rowgroups8(4), 2))) return rc;
-    if ((rc = upload_steps(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1), 4))) return rc;
-    if ((rc = upload_steps(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1), 4))) return rc;
-    if ((rc = upload_steps(c, "steps.rows8kd", steps_rows8_kd(), 8))) return rc;
+    if ((rc = upload_steps(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
+    if ((rc = upload_steps(c, "steps.rowgroups8_4", steps_rowgroups8(4)))) return rc;
+    if ((rc = upload_steps(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1)))) return rc;
+    if ((rc = upload_steps(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1)))) return rc;
+    if ((rc = upload_steps(c, "steps.rows8kd", steps_rows8_kd()))) return rc;
     {
         // decoder stem as a per-(tap, code) partial-sum table (stem_lut_k), built on the device once
         float* T = nullptr;
@@ -681,6 +677,16 @@ void launch_latent_assign(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx
     else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2, split > 1 ? split : 1), dim3(128), LDS_LATENT, s, A); });
 }
 
+// gridDim.y for a position-split launch of `wgs` workgroups: enough ranges to reach `target` workgroups (about two rounds
+// of what the chip holds at once given the kernel's LDS / register footprint), at least `lo` (the factor used near the
+// crossover), at most the kernel's number of output groups (a power of two)
+int split_factor(int wgs, int lo, int n_groups, int target)
+{
+    int ps = lo;
+    while (ps < n_groups && (int64_t)wgs * ps < target) ps *= 2;
+    return std::min(ps, n_groups);
+}
+
 // Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
 // od-slabs split over gridDim.y workgroups, activations are stored, and the GroupNorm / channel-sum statistics are
 // recomputed by sequential kernels in the contract's order.  Same results bit for bit, ~5x lower latency.
@@ -689,13 +695,13 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     const int nt = (int)((n + 31) / 32);
     auto& a = c->act;
     auto& w = c->dw;
-    auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".od"]); };
+    auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
     const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
     {
         ConvArgs A{};
         A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rows8kd"], A.od_start = od("steps.rows8kd");
-        L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, 8), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd");
+        L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         L.run("enc_stats_y1", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 4>), dim3(nt), dim3(128), 0, s, a["e_y1"], a["st_a.mean"], a["st_a.rstd"]); });
         L.run("enc_gn_relu_a1", [&] {
             hipLaunchKernelGGL((ew_gn_relu_k<16, 512, 4>), dim3(nt, 16), dim3(256), 0, s, a["e_y1"], a["e_a1"], a["st_a.mean"], a["st_a.rstd"], w["eg0.w"], w["eg0.b"]);
@@ -706,40 +712,40 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         ConvArgs A{};
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.od_start = od("steps.rowgroups8_4");
-        L.run("enc_res16_conv1_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, false>), dim3((2 * nt + 3) / 4, 8), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.grp_start = od("steps.rowgroups8_4");
+        L.run("enc_res16_conv1_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, false>), dim3((2 * nt + 3) / 4, split_factor((2 * nt + 3) / 4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
         L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 2>), dim3(nt), dim3(128), 0, s, a["e_y4"], a["st_a.mean"], a["st_a.rstd"]); });
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
-        L.run("enc_res16_conv2_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4, 8), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        L.run("enc_res16_conv2_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4, split_factor((2 * nt + 3) / 4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.od_start = od("steps.rows_k4s2_8");
-        L.run("enc_down_s", [&] { hipLaunchKernelGGL(k_enc_down_s, dim3(g2, 4), dim3(128), LDS_ENC_DOWN, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
+        A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.grp_start = od("steps.rows_k4s2_8");
+        L.run("enc_down_s", [&] { hipLaunchKernelGGL(k_enc_down_s, dim3(g2, split_factor(g2, 4, 16, 512)), dim3(128), LDS_ENC_DOWN, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
         L.run("enc_stats_x7", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_x7"], a["st_b.mean"], a["st_b.rstd"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.od_start = od("steps.rows_k3_4");
-        L.run("enc_res32_conv1_s", [&] { hipLaunchKernelGGL(k_enc_r32c1_s, dim3(g2, 4), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
+        L.run("enc_res32_conv1_s", [&] { hipLaunchKernelGGL(k_enc_r32c1_s, dim3(g2, split_factor(g2, 4, 16, 512)), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
         L.run("enc_stats_y9", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_y9"], a["st_a.mean"], a["st_a.rstd"]); });
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
-        L.run("enc_res32_conv2_s", [&] { hipLaunchKernelGGL(k_enc_r32c2_s, dim3(g2, 4), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv2_s", [&] { hipLaunchKernelGGL(k_enc_r32c2_s, dim3(g2, split_factor(g2, 4, 16, 512)), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
         L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"]); });
     }
     if (d_latent) {
-        launch_latent_assign(c, L, n, d_idx, d_latent, s, 8);
+        launch_latent_assign(c, L, n, d_idx, d_latent, s, split_factor(g2, 8, 32, 512));
         return L.rc;
     }
     VqArgs A{};
     A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
     A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
-    L.run("enc_vq_s", [&] { hipLaunchKernelGGL(vq_folded_k<2>, dim3(g2, 8), dim3(128), 0, s, A); });
+    L.run("enc_vq_s", [&] { hipLaunchKernelGGL(vq_folded_k<2>, dim3(g2, split_factor(g2, 8, 32, 2048)), dim3(128), 0, s, A); });
     return L.rc;
 }
 
@@ -822,10 +828,10 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
     const int nt = (int)((n + 31) / 32);
     auto& a = c->act;
     auto& w = c->dw;
-    auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".od"]); };
+    auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
     const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
     L.run("dec_stem_s", [&] {
-        hipLaunchKernelGGL(stem_lut_k, dim3(g4, 4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
+        hipLaunchKernelGGL(stem_lut_k, dim3(g4, split_factor(g4, 4, 16, 1024)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
                            (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"));
     });
     L.run("dec_stats_ystem", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_ystem"], a["st_a.mean"], a["st_a.rstd"]); });
@@ -837,19 +843,19 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         ConvArgs A{};
         A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27, A.od_start = od("steps.k3s1_4");
-        L.run("dec_res64_conv1_s", [&] { hipLaunchKernelGGL(k_dec_r64c1_s, dim3(g2, 4), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27, A.grp_start = od("steps.k3s1_4");
+        L.run("dec_res64_conv1_s", [&] { hipLaunchKernelGGL(k_dec_r64c1_s, dim3(g2, split_factor(g2, 4, 16, 1024)), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
         L.run("dec_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_y4"], a["st_a.mean"], a["st_a.rstd"]); });
         A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w"], A.bias_frag = w["r64c2.b"], A.skip = a["d_d2"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
-        L.run("dec_res64_conv2_s", [&] { hipLaunchKernelGGL(k_dec_r64c2_s, dim3(g2, 4), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        L.run("dec_res64_conv2_s", [&] { hipLaunchKernelGGL(k_dec_r64c2_s, dim3(g2, split_factor(g2, 4, 16, 1024)), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
         L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"]); });
     }
     {
         ConvArgs A{};
         A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
-        A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.od_start = od("steps.tail");
+        A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
         L.run("dec_tail_s", [&] { hipLaunchKernelGGL(k_dec_tail_s, dim3(g2, 4), dim3(128), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
     }
     return L.rc;
