@@ -153,9 +153,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (tests/tools only): every rank uses cuda:0 and the process
+    # group runs on gloo (RCCL refuses two ranks on one device).  The numbers of such a run are meaningless.
+    rehearsal = os.environ.get("VQ_BENCH_SINGLE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     dist = world > 1 or os.environ.get("VQ_BENCH_FORCE_DIST") == "1"   # the latter exercises the RCCL path with one rank
     if dist:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif args.gpus != 1:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     device = torch.device("cuda", local)
@@ -218,7 +226,8 @@ def main():
             trainer = CodebookTrainer(tcodec, device=str(device))
             train = {"note": "VectorQuantizerEMA training-mode step on encoder outputs (encoder forward + latent + assign + "
                              "statistics + all-reduce + EMA update); encoder/decoder weights frozen; not the headline value",
-                     "collective": f"all_reduce(SUM) of 33281 fp32 over {world} rank(s), RCCL" if dist else "none (1 rank)"}
+                     "collective": (f"all_reduce(SUM) of 33281 fp32 over {world} rank(s), "
+                                    f"{'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()}") if dist else "none (1 rank)"}
             ksteps = max(2, min(args.steps, 8))
             for per_rank in (2048, BATCH):
                 x = leaves[0][:per_rank]
@@ -264,7 +273,9 @@ def main():
             "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_enc / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1xMI355X, 1M synthetic leaves in 65536-leaf batches, fp32 encoder+quantizer, K=256 D=128",
+            "config": {"workload": ("BASELINE configs[1]: 1xMI355X, 1M synthetic leaves in 65536-leaf batches, fp32 encoder+quantizer, K=256 D=128" if world == 1 else
+                                    f"BASELINE configs[3] shape: {world}xMI355X encode, leaves sharded across GPUs (65536-leaf batches per GPU per step), "
+                                    "fp32 encoder+quantizer, K=256 D=128"),
                        "leaves_per_step_per_gpu": BATCH, "sharding": f"leaves sharded over {world} rank(s), no collective"},
             "roofline": roofline_of(ek, ENC_FLOP, enc_lps / world),
             "cpu_baseline": cpu,

@@ -335,3 +335,26 @@ def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
         assert np.array_equal(ia, oracle.encode(leaves, threads=16))
     assert np.array_equal(_bits(a.decode(ia)), _bits(b.decode(ib)))
     a.close(), b.close()
+
+
+def test_bench_two_rank_code_path_rehearsal():
+    """bench.py's N > 1 path (rank-sharded seeds, barriers, max-over-ranks timing, all-reduce of the codebook statistics,
+    one JSON line from rank 0) launched exactly like the driver does, with two ranks sharing the one GPU of this box
+    (gloo instead of RCCL; the throughput of such a run means nothing)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VQ_BENCH_SINGLE_GPU_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["decode"]["value"] > 0
+    ct = d["codebook_training"]
+    assert "error" not in ct and "over 2 rank(s)" in ct["collective"] and ct["per_rank_batch_2048"]["leaves_per_s"] > 0
