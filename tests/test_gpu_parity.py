@@ -358,3 +358,24 @@ def test_bench_two_rank_code_path_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["decode"]["value"] > 0
     ct = d["codebook_training"]
     assert "error" not in ct and "over 2 rank(s)" in ct["collective"] and ct["per_rank_batch_2048"]["leaves_per_s"] > 0
+
+
+def test_one_handle_mixed_batch_sizes_no_stale_state(pack, oracle):
+    """A long-lived handle (the SOP node cache) sees batches of any size in any order: the split path, the one-wave-per-tile
+    path, multi-chunk calls and workspace growth share the statistics / activation buffers and must not leak state."""
+    rng = np.random.default_rng(11)
+    c = HipCodec(pack)
+    c.set_chunk_leaves(4096)                                  # 21000 leaves -> 6 chunks; 4096-leaf chunks take the split path
+    sizes = [5, 21000, 64, 3000, 1, 4097, 2048, 33]
+    base = synth.make_leaves(2048, seed=4242)
+    base_idx = oracle.encode(base, threads=16)
+    base_rec = oracle.decode(base_idx, threads=16)
+    for step, n in enumerate(sizes):
+        if step == 4:
+            c.set_chunk_leaves(65536)
+            c.set_small_batch_tiles(16)                       # now only <= 512 leaves split (encode), <= 1024 (decode)
+        pick = rng.integers(0, 2048, size=n)
+        idx = c.encode(base[pick])
+        assert np.array_equal(idx, base_idx[pick]), (step, n)
+        assert np.array_equal(_bits(c.decode(idx)), _bits(base_rec[pick])), (step, n)
+    c.close()
