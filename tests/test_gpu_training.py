@@ -133,3 +133,29 @@ def test_validation_forward_matches_reference(tcodec, gt):  # noqa: F811
     assert not np.array_equal(before["embedding"], after["embedding"]) and m2["vq_loss"] != m["vq_loss"]
     m3 = tr.evaluate(torch.from_numpy(synth.make_leaves(64, seed=4100)).cuda())
     assert m3 == m2 and all(np.array_equal(after[k], tcodec.train_get_state()[k]) for k in after)
+
+
+def test_checkpoint_resume_is_bit_identical(weights):
+    """state_dict -> a fresh handle -> load_state_dict continues exactly like the uninterrupted run (SURVEY §5 checkpoint row)."""
+    batches = [torch.from_numpy(synth.make_leaves(300, seed=80 + s)).cuda() for s in range(3)]
+    a = HipCodec(weightpack.dumps(weights))
+    ta = CodebookTrainer(a)
+    for b in batches:
+        ta.step(b)
+    b_codec = HipCodec(weightpack.dumps(weights))
+    tb = CodebookTrainer(b_codec)
+    for b in batches[:2]:
+        tb.step(b)
+    sd = {k: v.copy() for k, v in tb.state_dict().items()}
+    b_codec.close()
+    c = HipCodec(weightpack.dumps(weights))          # pack still holds the ORIGINAL codebook: everything comes from the checkpoint
+    tc = CodebookTrainer(c)
+    tc.load_state_dict(sd)
+    m = tc.step(batches[2])
+    want, got = ta.state_dict(), tc.state_dict()
+    for k in want:
+        assert np.array_equal(_bits(want[k]), _bits(got[k])), k
+    assert m["rows"] == 300 * 64
+    leaves = synth.make_leaves(50, seed=3)
+    assert np.array_equal(a.encode(leaves), c.encode(leaves))
+    a.close(), c.close()

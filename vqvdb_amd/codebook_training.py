@@ -146,6 +146,11 @@ class CodebookTrainer:
         """quantizer.* buffers in the reference's state_dict naming (VQVAE_v2.py:103-105)."""
         return {f"quantizer.{k}": v for k, v in self.codec.train_get_state().items()}
 
+    def load_state_dict(self, sd: dict):
+        """Resume from quantizer.* buffers saved by state_dict() or by the reference's checkpoints (training.py:216-233)."""
+        self.codec.train_set_state(embedding=sd["quantizer.embedding"], cluster_size=sd["quantizer.cluster_size"],
+                                   embed_avg=sd["quantizer.embed_avg"])
+
     def finish(self):
         """Refresh the inference tables (folded search, decoder stem table) from the trained codebook."""
         self.codec.train_commit()
