@@ -159,3 +159,51 @@ def test_checkpoint_resume_is_bit_identical(weights):
     leaves = synth.make_leaves(50, seed=3)
     assert np.array_equal(a.encode(leaves), c.encode(leaves))
     a.close(), c.close()
+
+
+def test_epoch_driver_trains_validates_and_checkpoints(weights, tmp_path):
+    """vqvdb_amd.train_codebook: two short epochs on synthetic leaves; the loop shape of training.py (train pass, validation,
+    best-val checkpoint, final save) and a codebook that fits the data better after training."""
+    from vqvdb_amd import train_codebook
+    (tmp_path / "m.vqw").write_bytes(weightpack.dumps(weights))
+    out = train_codebook.main(["train", "--pack", str(tmp_path / "m.vqw"), "--epochs", "2", "--batch_size", "1024", "--leaves_per_epoch", "16384",
+                               "--model_path", str(tmp_path / "ckpt" / "quantizer.npz"), "--log_every", "4"])
+    h = out["history"]
+    assert len(h) == 2 and out["steps_per_epoch"] == 16 and h[0]["leaves_per_s"] > 0
+    assert h[1]["train_vq_loss"] < h[0]["train_vq_loss"] and h[1]["val_vq_loss"] < 0.02
+    best = np.load(tmp_path / "ckpt" / "quantizer.npz")
+    final = np.load(tmp_path / "ckpt" / "quantizer_final.npz")
+    for k in ("quantizer.embedding", "quantizer.cluster_size", "quantizer.embed_avg"):
+        assert best[k].shape == final[k].shape
+    assert not np.array_equal(final["quantizer.embedding"], weights["quantizer.embedding"])
+    # the saved codebook drops into a weight pack for inference
+    w2 = dict(weights)
+    w2["quantizer.embedding"] = final["quantizer.embedding"]
+    c = HipCodec(weightpack.dumps(w2))
+    leaves = synth.make_leaves(40, seed=1)
+    assert np.array_equal(c.encode(leaves), Oracle(w2, [t[0] for t in synth.TENSORS]).encode(leaves, threads=8))
+    c.close()
+
+
+def test_epoch_driver_two_rank_rehearsal(weights, tmp_path):
+    """The data-parallel loop of vqvdb_amd.train_codebook with two ranks sharing this box's GPU (gloo): both ranks apply the
+    all-reduced statistics, so the rank-0 checkpoint equals a single-rank run over the same global batches up to the
+    all-reduce's summation order."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "m.vqw").write_bytes(weightpack.dumps(weights))
+    common = ["train", "--pack", str(tmp_path / "m.vqw"), "--epochs", "1", "--leaves_per_epoch", "16384", "--log_every", "2"]
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29700 + os.getpid() % 200), "-m", "vqvdb_amd.train_codebook", *common, "--batch_size", "512",
+                        "--backend", "gloo", "--single_gpu_rehearsal", "--model_path", str(tmp_path / "two.npz")],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "2 rank(s) x batch 512" in r.stdout and "Training completed!" in r.stdout
+    from vqvdb_amd import train_codebook
+    train_codebook.main([*common, "--batch_size", "1024", "--model_path", str(tmp_path / "one.npz")])
+    one, two = np.load(tmp_path / "one_final.npz"), np.load(tmp_path / "two_final.npz")
+    for k in ("quantizer.embedding", "quantizer.cluster_size", "quantizer.embed_avg"):
+        err = np.abs(one[k].astype(np.float64) - two[k]).max() / np.abs(one[k]).max()
+        assert err < 1e-5, (k, err)
