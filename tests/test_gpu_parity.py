@@ -379,3 +379,17 @@ def test_one_handle_mixed_batch_sizes_no_stale_state(pack, oracle):
         assert np.array_equal(idx, base_idx[pick]), (step, n)
         assert np.array_equal(_bits(c.decode(idx)), _bits(base_rec[pick])), (step, n)
     c.close()
+
+
+def test_denormal_and_tiny_inputs_match_oracle(codec, oracle):
+    """fp32 subnormals are preserved by the MFMA path exactly like the CPU restatement's fmaf chain (no flush-to-zero)."""
+    rng = np.random.default_rng(5)
+    leaves = np.stack([
+        (rng.random(512) * 1e-39).astype(np.float32),                       # all subnormal
+        np.where(rng.random(512) < 0.5, 1e-42, 0.0).astype(np.float32),     # sparse subnormal spikes
+        (rng.random(512) * 1e-30).astype(np.float32),                       # tiny normals whose products underflow
+        np.full(512, np.float32(1.17549435e-38)),                           # smallest normal
+    ])
+    idx = codec.encode(leaves)
+    assert np.array_equal(idx, oracle.encode(leaves, threads=4))
+    assert np.array_equal(_bits(codec.decode(idx)), _bits(oracle.decode(idx, threads=4)))
