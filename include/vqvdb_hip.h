@@ -184,6 +184,18 @@ int vqhip_train_set_state(vqhip_codec* codec, const float* embedding, const floa
  * entry points do this on demand; calling it explicitly keeps the cost out of the first encode/decode. */
 int vqhip_train_commit(vqhip_codec* codec);
 
+/* ---- full training step (extension; SURVEY.md §8 f-2, stage 2; python/training.py:47-258) -------------------------
+ * fp32 forward + backward + AdamW for the encoder / decoder weights, EMA for the codebook.  In progress: see DESIGN.md §6c
+ * for what is wired.  Parameters live in one flat vector in the reference's parameter order (vqhip_fulltrain_param_count). */
+int vqhip_fulltrain_begin(vqhip_codec* codec);
+int64_t vqhip_fulltrain_param_count(const vqhip_codec* codec);
+/* Training-mode forward only (test hook): every activation stays in the workspaces for vqhip_debug_fetch. */
+int vqhip_fulltrain_forward_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, void* hip_stream);
+/* Forward + backward of this rank's batch: gradients of loss = 0.8 mse + 0.2 l1 + vq_loss (means over n_global leaves) into
+ * grads_dev (flat, parameter order).  The host all-reduces grads_dev across ranks before the optimizer step. */
+int vqhip_fulltrain_fwdbwd_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, int64_t n_global_leaves, float* grads_dev,
+                                  void* hip_stream);
+
 /* ---- measurement hooks (bench.py / tests) ---- */
 
 /* Per-kernel timing with HIP events on the launch stream.  While enabled, every kernel

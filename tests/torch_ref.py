@@ -9,13 +9,22 @@ import torch
 import torch.nn.functional as F
 
 
+def _rec(tape, name, t):
+    """Optionally record an intermediate (and keep its gradient) under `name`."""
+    if tape is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        tape[name] = t
+    return t
+
+
 def _gn_relu(x, w, prefix, groups):
     return F.relu(F.group_norm(x, groups, w[prefix + ".weight"], w[prefix + ".bias"], eps=1e-5))
 
 
-def _res_block(x, w, prefix, groups=8, scale=0.1):
+def _res_block(x, w, prefix, groups=8, scale=0.1, tape=None, tag=""):
     t = _gn_relu(x, w, prefix + ".gn1", groups)
-    y = F.conv3d(t, w[prefix + ".conv1.weight"], w[prefix + ".conv1.bias"], padding=1)
+    y = _rec(tape, tag + ".y", F.conv3d(t, w[prefix + ".conv1.weight"], w[prefix + ".conv1.bias"], padding=1))
     u = _gn_relu(y, w, prefix + ".gn2", groups)
     return x + scale * F.conv3d(u, w[prefix + ".conv2.weight"], w[prefix + ".conv2.bias"], padding=1)
 
@@ -26,12 +35,13 @@ def _attention(x, w, prefix):
     return x * g[:, :, None, None, None]
 
 
-def encoder(x, w):
-    a = _gn_relu(F.conv3d(x, w["encoder.pre.0.weight"], w["encoder.pre.0.bias"], padding=1), w, "encoder.pre.1", 4)
-    a = _res_block(a, w, "encoder.pre.3")
-    a = F.conv3d(a, w["encoder.down.weight"], w["encoder.down.bias"], stride=2, padding=1)
-    a = _res_block(a, w, "encoder.res_stack.0")
-    a = _attention(a, w, "encoder.attn")
+def encoder(x, w, tape=None):
+    y1 = _rec(tape, "e.y1", F.conv3d(x, w["encoder.pre.0.weight"], w["encoder.pre.0.bias"], padding=1))
+    a = _rec(tape, "e.a1", _gn_relu(y1, w, "encoder.pre.1", 4))
+    a = _rec(tape, "e.a6", _res_block(a, w, "encoder.pre.3", tape=tape, tag="e.r16"))
+    a = _rec(tape, "e.x7", F.conv3d(a, w["encoder.down.weight"], w["encoder.down.bias"], stride=2, padding=1))
+    a = _rec(tape, "e.x11", _res_block(a, w, "encoder.res_stack.0", tape=tape, tag="e.r32"))
+    a = _rec(tape, "e.x12", _attention(a, w, "encoder.attn"))
     return F.conv3d(a, w["encoder.proj.weight"], w["encoder.proj.bias"])
 
 
@@ -41,12 +51,14 @@ def pixel_shuffle3d(x, r=2):
     return x.view(b, oc, r, r, r, d, h, wd).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(b, oc, d * r, h * r, wd * r)
 
 
-def decoder(q, w):
-    a = _gn_relu(F.conv3d(q, w["decoder.stem.0.weight"], w["decoder.stem.0.bias"], padding=1), w, "decoder.stem.1", 8)
-    a = _res_block(a, w, "decoder.res_stack.0")
-    a = _attention(a, w, "decoder.attn")
-    a = pixel_shuffle3d(F.conv3d(a, w["decoder.up_conv.weight"], w["decoder.up_conv.bias"], padding=1))
-    return torch.sigmoid(F.conv3d(a, w["decoder.final.weight"], w["decoder.final.bias"], padding=1))
+def decoder(q, w, tape=None):
+    ys = _rec(tape, "d.ys", F.conv3d(q, w["decoder.stem.0.weight"], w["decoder.stem.0.bias"], padding=1))
+    a = _rec(tape, "d.d2", _gn_relu(ys, w, "decoder.stem.1", 8))
+    a = _rec(tape, "d.x6", _res_block(a, w, "decoder.res_stack.0", tape=tape, tag="d.r64"))
+    a = _rec(tape, "d.x7", _attention(a, w, "decoder.attn"))
+    up = _rec(tape, "d.up", F.conv3d(a, w["decoder.up_conv.weight"], w["decoder.up_conv.bias"], padding=1))
+    pre = _rec(tape, "d.pre", F.conv3d(pixel_shuffle3d(up), w["decoder.final.weight"], w["decoder.final.bias"], padding=1))
+    return torch.sigmoid(pre)
 
 
 def quantize(z, codebook, commitment_cost=0.25):
@@ -59,11 +71,12 @@ def quantize(z, codebook, commitment_cost=0.25):
     return z + (q - z).detach(), loss, idx
 
 
-def training_loss(x, w, commitment_cost=0.25, mse_weight=0.8, l1_weight=0.2):
-    """Forward of one training step: returns (loss, dict of pieces).  x: [B,1,8,8,8]."""
-    z = encoder(x, w)
+def training_loss(x, w, commitment_cost=0.25, mse_weight=0.8, l1_weight=0.2, tape=None):
+    """Forward of one training step: returns (loss, dict of pieces).  x: [B,1,8,8,8].  tape: dict receiving intermediates."""
+    z = _rec(tape, "z", encoder(x, w, tape))
     q, vq_loss, idx = quantize(z, w["quantizer.embedding"], commitment_cost)
-    recon = decoder(q, w)
+    q = _rec(tape, "q", q)
+    recon = decoder(q, w, tape)
     mse, l1 = F.mse_loss(recon, x), F.l1_loss(recon, x)
     loss = mse_weight * mse + l1_weight * l1 + vq_loss
     return loss, {"z": z, "idx": idx, "recon": recon, "mse": mse, "l1": l1, "vq_loss": vq_loss}

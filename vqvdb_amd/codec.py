@@ -91,6 +91,7 @@ ABI_SYMBOLS = [
     "vqhip_decompress_file", "vqhip_compress_file", "vqhip_reserve",
     "vqhip_train_begin", "vqhip_train_vq_stats_device", "vqhip_train_vq_update_device", "vqhip_train_get_state", "vqhip_train_set_state",
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
+    "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -150,6 +151,11 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_train_get_state.argtypes = [vp, vp, vp, vp]
     lib.vqhip_train_set_state.argtypes = [vp, vp, vp, vp]
     lib.vqhip_train_commit.argtypes = [vp]
+    lib.vqhip_fulltrain_begin.argtypes = [vp]
+    lib.vqhip_fulltrain_param_count.argtypes = [vp]
+    lib.vqhip_fulltrain_param_count.restype = i64
+    lib.vqhip_fulltrain_forward_device.argtypes = [vp, vp, i64, vp]
+    lib.vqhip_fulltrain_fwdbwd_device.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
     lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
     lib.vqhip_debug_enable.argtypes = [vp, ci]
@@ -166,7 +172,8 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_decompress_file.argtypes = [vp, ctypes.c_char_p, i64, GRID_BEGIN_FN, LEAF_ALLOC_FN, vp, ctypes.POINTER(StreamStats)]
     lib.vqhip_compress_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(_GridSource), ci, i64, ctypes.POINTER(StreamStats)]
     for name in ABI_SYMBOLS:
-        if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error"):
+        if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error",
+                        "vqhip_fulltrain_param_count"):
             getattr(lib, name).restype = ci
     _lib = lib
     return lib
@@ -336,6 +343,25 @@ class HipCodec:
 
     def set_small_batch_tiles(self, tiles: int):
         self._check(self._lib.vqhip_set_small_batch_tiles(self._h, tiles))
+
+    # ---- full training step (stage 2, in progress) ----
+    def fulltrain_begin(self):
+        self._check(self._lib.vqhip_fulltrain_begin(self._h))
+
+    def fulltrain_param_count(self) -> int:
+        return int(self._lib.vqhip_fulltrain_param_count(self._h))
+
+    def fulltrain_forward_device(self, leaves_ptr: int, n: int, stream: int = 0):
+        self._check(self._lib.vqhip_fulltrain_forward_device(self._h, leaves_ptr, n, stream or None))
+
+    def fulltrain_fwdbwd_device(self, leaves_ptr: int, n: int, n_global: int, grads_ptr: int, stream: int = 0):
+        self._check(self._lib.vqhip_fulltrain_fwdbwd_device(self._h, leaves_ptr, n, n_global, grads_ptr, stream or None))
+
+    def fetch(self, name: str, n: int, channels: int, positions: int) -> np.ndarray:
+        """debug_fetch without the debug flag: any named workspace tensor as [n, channels, positions]."""
+        out = np.empty((n, channels, positions), dtype=np.float32)
+        self._check(self._lib.vqhip_debug_fetch(self._h, name.encode(), n, out.ctypes.data))
+        return out
 
     def reserve(self, n: int):
         self._check(self._lib.vqhip_reserve(self._h, n))

@@ -1,0 +1,641 @@
+// vq_grad_kernels.h — kernels of the full training step (stage 2): training-mode forward pieces that the
+// inference path folds away (real stem conv input, unfolded up_conv / PixelShuffle3D / final, python/VQVAE_v2.py:253-275),
+// the loss of python/training.py:147-155, and the backward of every layer.  fp32 throughout; activations and gradients in
+// the leaf-tile ("L4") layout of vq_device.h, single-channel tensors as [tile][512][32].
+// Gradients are validated against PyTorch autograd of a plain fp32 restatement (tests/torch_ref.py), which is pinned to the
+// imported reference.  Reductions over leaves are done as per-tile (or per-group) partials + an ordered reduce: deterministic.
+#pragma once
+#include "vq_device.h"
+
+// ------------------------------------------------------------------------------------------
+// Weight fragments rebuilt on the device after every optimizer step (same index maps as the host builders in vq_runtime.hip).
+// W is the raw PyTorch tensor [OC][IC][KT].  transpose = 0: forward fragments of rows [row0, row0+COUT) x CIN=IC.
+// transpose = 1: fragments of the data-gradient conv (stride 1): COUT' = IC, CIN' = sub-range [row0,row0+CIN) of OC, taps flipped.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refrag32_k(const float* __restrict__ W, float* __restrict__ dst, int COUT, int CIN, int KT, int IC, int row0,
+                                                  int transpose, float scale)
+{
+    const int NU = CIN / 8, NMT = COUT / 32;
+    const int64_t total = (int64_t)KT * NU * NMT * 64 * 4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int i = t & 3, lane = (t >> 2) & 63;
+        int64_t r = t >> 8;
+        const int mt = r % NMT;
+        r /= NMT;
+        const int u = r % NU, tap = (int)(r / NU);
+        const int co = 32 * mt + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + i;
+        const float v = transpose ? W[((int64_t)(row0 + ci) * IC + co) * KT + (KT - 1 - tap)] : W[((int64_t)(row0 + co) * IC + ci) * KT + tap];
+        dst[t] = scale * v;
+    }
+}
+// 16x16x4 fragments for 16 -> 16 layers: [tap][lane][i] = W(co = lane&15, ci = 4(lane>>4)+i, tap)
+__global__ __launch_bounds__(256) void refrag16_k(const float* __restrict__ W, float* __restrict__ dst, int KT, int transpose, float scale)
+{
+    const int total = KT * 64 * 4;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int i = t & 3, lane = (t >> 2) & 63, tap = t >> 8;
+        const int co = lane & 15, ci = 4 * (lane >> 4) + i;
+        dst[t] = scale * (transpose ? W[(ci * 16 + co) * KT + (KT - 1 - tap)] : W[(co * 16 + ci) * KT + tap]);
+    }
+}
+__global__ __launch_bounds__(64) void refrag_first_k(const float* __restrict__ W, float* __restrict__ dst)
+{
+    const int lane = threadIdx.x, kw = lane >> 4;
+    for (int t = 0; t < 9; ++t) dst[t * 64 + lane] = kw < 3 ? W[(lane & 15) * 27 + t * 3 + kw] : 0.0f;
+}
+// D-fragment order of a per-cout vector: [(mt*2+q)*16 + r] = v[row0 + 32mt + (r&3) + 8(r>>2) + 4q]
+__global__ __launch_bounds__(256) void dfrag32_k(const float* __restrict__ v, float* __restrict__ dst, int COUT, int row0)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= COUT) return;
+    const int mt = f / 32, q = (f / 16) % 2, r = f % 16;
+    dst[f] = v[row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q];
+}
+
+// quantized latent as the decoder's input (F.embedding + permute, VQVAE_v2.py:127-131): q[tile][pos][32 quads][32][4] = E[idx[leaf][pos]]
+__global__ __launch_bounds__(256) void gather_codes_k(const uint8_t* __restrict__ idx, const float* __restrict__ E, float* __restrict__ q,
+                                                      int64_t n_leaves, int n_tiles)
+{
+    const int64_t total = (int64_t)n_tiles * 64 * 32 * 32;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int j = t & 31, quad = (t >> 5) & 31, pos = (t >> 10) & 63;
+        const int64_t tile = t >> 16, leaf = tile * 32 + j;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (leaf < n_leaves) v = ((const f32x4*)E)[(int)idx[leaf * 64 + pos] * 32 + quad];
+        ((f32x4*)q)[t] = v;
+    }
+}
+
+// ChannelAttention gates per (tile, channel, leaf) from the channel sums (VQVAE_v2.py:224-227): one wave per tile
+template <int C>
+__global__ __launch_bounds__(64) void se_gate_k(const float* __restrict__ csum, const float* __restrict__ fc0, const float* __restrict__ fc2,
+                                                float* __restrict__ gate)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x, j = lane & 31;
+    float hid[C / 4], g[C];
+    se_hidden<C>(csum + (size_t)tile * C * 32 + j, fc0, hid);
+    se_gates<C>(hid, fc2, g);
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) gate[((size_t)tile * C + c) * 32 + j] = g[c];
+    }
+}
+
+// pixel-shuffled view of the up_conv output (PixelShuffle3D(2), VQVAE_v2.py:172-187): channel c of the 32-channel 8^3 tensor at
+// voxel (D,H,W) is channel c*8 + (D&1)*4 + (H&1)*2 + (W&1) of the 256-channel 4^3 tensor at (D>>1,H>>1,W>>1).  The 256 channels
+// live in two 128-channel L4 tensors (up_conv runs as two 128-cout launches).
+__device__ __forceinline__ size_t ps_offset(int c, int D, int H, int W, int j)
+{
+    const int ch = c * 8 + (D & 1) * 4 + (H & 1) * 2 + (W & 1);
+    const int pos = ((D >> 1) * 4 + (H >> 1)) * 4 + (W >> 1);
+    return (((size_t)pos * 32 + ((ch & 127) >> 2)) * 32 + j) * 4 + (ch & 3);  // within one tile of the half (ch >> 7)
+}
+
+// final conv 32 -> 1, k3 p1 @8^3 on the pixel-shuffled tensor (VQVAE_v2.py:269,275) and sigmoid.  VALU: 864 MAC per voxel.
+// block = 32 leaves x 8 voxels of one tile; grid (tile, 64).
+__global__ __launch_bounds__(256) void final_fwd_k(const float* __restrict__ upA, const float* __restrict__ upB, const float* __restrict__ Wf,
+                                                   const float* __restrict__ bf, float* __restrict__ pre, float* __restrict__ recon)
+{
+    __shared__ float w[864];
+    for (int i = threadIdx.x; i < 864; i += 256) w[i] = Wf[i];
+    __syncthreads();
+    const int tile = blockIdx.x, j = threadIdx.x & 31;
+    const int P = blockIdx.y * 8 + (threadIdx.x >> 5), D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
+    const float* a = upA + (size_t)tile * 64 * 32 * 128;
+    const float* b = upB + (size_t)tile * 64 * 32 * 128;
+    float acc = 0.0f;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int d = D + kd - 1;
+        if (d < 0 || d > 7) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = H + kh - 1;
+            if (h < 0 || h > 7) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int x = Wd + kw - 1;
+                if (x < 0 || x > 7) continue;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll 8
+                for (int c = 0; c < 32; ++c) {
+                    const float v = (c < 16 ? a : b)[ps_offset(c, d, h, x, j)];
+                    acc = __builtin_fmaf(w[c * 27 + tap], v, acc);
+                }
+            }
+        }
+    }
+    acc = acc + bf[0];
+    pre[((size_t)tile * 512 + P) * 32 + j] = acc;
+    recon[((size_t)tile * 512 + P) * 32 + j] = vq_sigmoid(acc);
+}
+
+// d(loss)/d(pre) for loss = 0.8*mse + 0.2*l1 over N voxels (python/training.py:147-155): c_mse = 1.6/N, c_l1 = 0.2/N
+__global__ __launch_bounds__(256) void loss_grad_k(const float* __restrict__ x, const float* __restrict__ recon, float* __restrict__ dpre, float c_mse,
+                                                   float c_l1, int64_t n_leaves, int n_tiles)
+{
+    const int64_t total = (int64_t)n_tiles * 512 * 32;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t leaf = (t >> 14) * 32 + (t & 31);
+        float g = 0.0f;
+        if (leaf < n_leaves) {
+            const float r = recon[t], d = r - x[t];
+            g = (c_mse * d + (d > 0.0f ? c_l1 : (d < 0.0f ? -c_l1 : 0.0f))) * (r * (1.0f - r));
+        }
+        dpre[t] = g;
+    }
+}
+// sums of (recon-x)^2 and |recon-x| over the real leaves in the tile layout: partials per block, ordered reduce by the caller
+__global__ __launch_bounds__(256) void loss_sums_k(const float* __restrict__ x, const float* __restrict__ recon, int64_t n_leaves, int n_tiles,
+                                                   double* __restrict__ part /*[gridDim.x][2]*/)
+{
+    __shared__ double s2[256], s1[256];
+    double a2 = 0.0, a1 = 0.0;
+    const int64_t total = (int64_t)n_tiles * 512 * 32;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t leaf = (t >> 14) * 32 + (t & 31);
+        if (leaf < n_leaves) {
+            const double d = (double)recon[t] - (double)x[t];
+            a2 = fma(d, d, a2);
+            a1 += d < 0.0 ? -d : d;
+        }
+    }
+    s2[threadIdx.x] = a2;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s2[threadIdx.x] += s2[threadIdx.x + w];
+            s1[threadIdx.x] += s1[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = s2[0];
+        part[2 * blockIdx.x + 1] = s1[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// final conv backward (32 -> 1, k3 p1 @8^3 over the pixel-shuffled tensor)
+// ------------------------------------------------------------------------------------------
+// data gradient, written straight into the up_conv-output layout (PixelShuffle3D backward is the same index map)
+__global__ __launch_bounds__(256) void final_bwd_data_k(const float* __restrict__ dpre, const float* __restrict__ Wf, float* __restrict__ dupA,
+                                                        float* __restrict__ dupB)
+{
+    __shared__ float w[864];
+    for (int i = threadIdx.x; i < 864; i += 256) w[i] = Wf[i];
+    __syncthreads();
+    const int tile = blockIdx.x, j = threadIdx.x & 31;
+    const int P = blockIdx.y * 8 + (threadIdx.x >> 5), D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
+    float g[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        // ps[c][P] fed pre[P - off(t)] with weight W[c][t]
+        const int d = D - (t / 9 - 1), h = H - ((t / 3) % 3 - 1), x = Wd - (t % 3 - 1);
+        g[t] = (d >= 0 && d < 8 && h >= 0 && h < 8 && x >= 0 && x < 8) ? dpre[((size_t)tile * 512 + (d * 8 + h) * 8 + x) * 32 + j] : 0.0f;
+    }
+    float* a = dupA + (size_t)tile * 64 * 32 * 128;
+    float* b = dupB + (size_t)tile * 64 * 32 * 128;
+    for (int c = 0; c < 32; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) s = __builtin_fmaf(w[c * 27 + t], g[t], s);
+        (c < 16 ? a : b)[ps_offset(c, D, H, Wd, j)] = s;
+    }
+}
+// weight + bias gradient partials per tile: part[tile][865] ([c*27+tap], last = bias).  8 waves, wave w owns channels 4w..4w+3.
+__global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ dpre, const float* __restrict__ upA, const float* __restrict__ upB,
+                                                     float* __restrict__ part)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const float* src = (wave < 4 ? upA : upB) + (size_t)tile * 64 * 32 * 128;
+    float acc[27][4];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t][k] = 0.0f;
+    float bsum = 0.0f;
+    for (int P = 256 * h; P < 256 * h + 256; ++P) {
+        const float dp = dpre[((size_t)tile * 512 + P) * 32 + j];
+        bsum += dp;
+        const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int d = D + t / 9 - 1, hh = H + (t / 3) % 3 - 1, x = Wd + t % 3 - 1;
+            if (d < 0 || d > 7 || hh < 0 || hh > 7 || x < 0 || x > 7) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[t][k] = __builtin_fmaf(dp, src[ps_offset(4 * wave + k, d, hh, x, j)], acc[t][k]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = acc[t][k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) part[(size_t)tile * 865 + (4 * wave + k) * 27 + t] = v;
+        }
+    if (wave == 0) {
+        for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o, 64);
+        if (lane == 0) part[(size_t)tile * 865 + 864] = bsum;
+    }
+}
+// dst[i] = scale * sum over parts (ascending) of part[p][i]
+__global__ __launch_bounds__(256) void parts_reduce_k(const float* __restrict__ part, int n_parts, int n, float* __restrict__ dst, float scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + i];
+    dst[i] = scale * s;
+}
+// dst[c] = scale * sum over tiles and leaves of part[tile][c][32]  (bias / GroupNorm-affine gradients from per-(tile,channel,leaf) sums)
+__global__ __launch_bounds__(64) void chan_reduce_k(const float* __restrict__ part, int n_tiles, int C, float* __restrict__ dst, float scale)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s = 0.0f;
+    for (int t = 0; t < n_tiles; ++t)
+        if (lane < 32) s += part[((size_t)t * C + c) * 32 + lane];
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) dst[c] = scale * s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic weight gradient of a leaf-tile convolution: dW[co][ci][tap] = sum over leaves, valid (ip, po) pairs of the tap of
+// dY[po][co][leaf] * X'[ip][ci][leaf], X' = X, relu(GroupNorm(X)) or gate*X exactly as the forward kernel formed it on load.
+// The leaves are the MFMA K axis: the dY and X' blocks of one position pair are transposed through LDS ([channel][leaf], row
+// stride 33 floats -> conflict-free) and each wave accumulates one 32 x 32 (co, ci) block over ALL steps of its workgroup.
+// grid (taps, tile groups); wsteps = (ip, po) pairs sorted by tap, tap_start[t] their offsets.  Output: per-group partials
+// part[((grp*KT + tap)*COUT + co)*CIN + ci]; wgrad_reduce_k adds the groups in order and writes PyTorch's [OC][IC][KT] layout.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dy;      // L4 [tile][NPO][COUT/4][32][4]
+    const float* x;       // L4 [tile][NPI][CIN/4][32][4]
+    const float* mean;    // INMODE 1: [tile][GIN][32]
+    const float* rstd;
+    const float* gamma;   // [CIN]
+    const float* beta;
+    const float* gate;    // INMODE 2: [tile][CIN][32]
+    const int2* wsteps;
+    const int* tap_start;
+    float* part;
+    int n_tiles, tiles_per_group, KT;
+};
+
+template <int CIN, int COUT, int NPI, int NPO, int INMODE, int GIN>
+__global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void wgrad32_k(WgradArgs A)
+{
+    constexpr int CB = (COUT + 31) / 32, IB = (CIN + 31) / 32, NT = CB * IB * 64;
+    __shared__ float sdy[CB * 32][33];
+    __shared__ float sx[IB * 32][33];
+    for (int i = threadIdx.x; i < CB * 32 * 33; i += NT) (&sdy[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < IB * 32 * 33; i += NT) (&sx[0][0])[i] = 0.0f;
+    const int tap = blockIdx.x, grp = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
+    const int s0 = A.tap_start[tap], s1 = A.tap_start[tap + 1];
+    const int t0 = grp * A.tiles_per_group, t1 = min(A.n_tiles, t0 + A.tiles_per_group);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
+    for (int tile = t0; tile < t1; ++tile) {
+        for (int si = s0; si < s1; ++si) {
+            const int2 e = A.wsteps[si];  // x = input position, y = output position
+            __syncthreads();              // previous step's MFMAs have read the blocks
+            for (int i = threadIdx.x; i < (COUT / 4) * 32; i += NT) {
+                const int quad = i >> 5, leaf = i & 31;
+                const f32x4 v = ((const f32x4*)A.dy)[(((size_t)tile * NPO + e.y) * (COUT / 4) + quad) * 32 + leaf];
+                sdy[4 * quad + 0][leaf] = v.x, sdy[4 * quad + 1][leaf] = v.y, sdy[4 * quad + 2][leaf] = v.z, sdy[4 * quad + 3][leaf] = v.w;
+            }
+            for (int i = threadIdx.x; i < (CIN / 4) * 32; i += NT) {
+                const int quad = i >> 5, leaf = i & 31;
+                const f32x4 v = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + quad) * 32 + leaf];
+                float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ch = 4 * quad + k;
+                    if (INMODE == 1) {
+                        const int g = ch / CPG;
+                        const float ia = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
+                        const float ibb = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], ia, A.beta[ch]);
+                        o[k] = fmaxf(__builtin_fmaf(o[k], ia, ibb), 0.0f);
+                    } else if (INMODE == 2) {
+                        o[k] = o[k] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
+                    }
+                    sx[ch][leaf] = o[k];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                acc = mfma32(sdy[32 * cb + (lane & 31)][2 * m + (lane >> 5)], sx[32 * ib + (lane & 31)][2 * m + (lane >> 5)], acc);
+        }
+    }
+    float* dst = A.part + ((size_t)grp * A.KT + tap) * COUT * CIN;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = 32 * ib + (lane & 31);
+        if (co < COUT && ci < CIN) dst[(size_t)co * CIN + ci] = acc[r];
+    }
+}
+// dW[(row0+co)*IC + ci][tap] = scale * sum_grp part[grp][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ part, int n_groups, int KT, int COUT, int CIN, float* __restrict__ dW, int row0,
+                                                      int IC, float scale)
+{
+    const int64_t total = (int64_t)KT * COUT * CIN;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ci = t % CIN, co = (t / CIN) % COUT, tap = (int)(t / ((int64_t)CIN * COUT));
+        float s = 0.0f;
+        for (int g = 0; g < n_groups; ++g) s += part[(((size_t)g * KT + tap) * COUT + co) * CIN + ci];
+        dW[((size_t)(row0 + co) * IC + ci) * KT + tap] = scale * s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm + ReLU backward:  a = relu(gamma * xh + beta), xh = (x - mean) * rstd.  Given da:
+//   gi = [pre > 0] da gamma;  dx = rstd (gi - mean_grp(gi) - xh mean_grp(gi xh));  dgamma = sum [pre>0] da xh;  dbeta = sum [pre>0] da
+// pass 1 (gn_bwd_sums_k): per (leaf, group) S1 = sum gi, S2 = sum gi xh, and per (tile, channel, leaf) dgamma / dbeta partials;
+// pass 2 (gn_bwd_apply_k): elementwise, optionally adding the gradient of the skip path.  Thread mapping of gn_stats_seq_k.
+// ------------------------------------------------------------------------------------------
+template <int C, int NP, int CPG>
+__global__ __launch_bounds__(64 * C / 8) void gn_bwd_sums_k(const float* __restrict__ x, const float* __restrict__ da, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ dgam, float* __restrict__ dbet)
+{
+    constexpr int G = C / CPG;
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
+    const int tile = blockIdx.x;
+    float mu[4], rs[4], ia[4], ib[4], gm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ch = 4 * quad + k, g = ch / CPG;
+        mu[k] = mean[((size_t)tile * G + g) * 32 + j];
+        rs[k] = rstd[((size_t)tile * G + g) * 32 + j];
+        gm[k] = gamma[ch];
+        ia[k] = rs[k] * gm[k];
+        ib[k] = __builtin_fmaf(-mu[k], ia[k], beta[ch]);
+    }
+    const size_t base = (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int p = 0; p < NP; ++p) {
+        const f32x4 xv = ((const f32x4*)x)[base + (size_t)p * (C / 4) * 32];
+        const f32x4 dv = ((const f32x4*)da)[base + (size_t)p * (C / 4) * 32];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xs[k] - mu[k]) * rs[k];
+            const float d = __builtin_fmaf(xs[k], ia[k], ib[k]) > 0.0f ? ds[k] : 0.0f;
+            const float gi = d * gm[k];
+            a1[k] += gi;
+            a2[k] = __builtin_fmaf(gi, xh, a2[k]);
+            dg[k] = __builtin_fmaf(d, xh, dg[k]);
+            db[k] += d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dgam[((size_t)tile * C + 4 * quad + k) * 32 + j] = dg[k];
+        dbet[((size_t)tile * C + 4 * quad + k) * 32 + j] = db[k];
+    }
+    if (CPG == 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            s1[((size_t)tile * G + 2 * quad + k) * 32 + j] = a1[2 * k] + a1[2 * k + 1];
+            s2[((size_t)tile * G + 2 * quad + k) * 32 + j] = a2[2 * k] + a2[2 * k + 1];
+        }
+    } else {
+        float t1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), t2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+        if (CPG == 8) {
+            t1 += __shfl_xor(t1, 32, 64);
+            t2 += __shfl_xor(t2, 32, 64);
+        }
+        if (CPG == 4 || (lane >> 5) == 0) {
+            const int g = CPG == 4 ? quad : quad >> 1;
+            s1[((size_t)tile * G + g) * 32 + j] = t1;
+            s2[((size_t)tile * G + g) * 32 + j] = t2;
+        }
+    }
+}
+template <int C, int NP, int CPG>
+__global__ __launch_bounds__(256) void gn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ da, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ add,
+                                                      float* __restrict__ dx)
+{
+    constexpr int G = C / CPG;
+    constexpr float inv_n = 1.0f / (float)(CPG * NP);
+    const int tile = blockIdx.x;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < NP * (C / 4) * 32; i += gridDim.y * 256) {
+        const int j = i & 31, quad = (i >> 5) % (C / 4);
+        const size_t o = (size_t)tile * NP * (C / 4) * 32 + i;
+        const f32x4 xv = ((const f32x4*)x)[o], dv = ((const f32x4*)da)[o];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = 4 * quad + k, g = ch / CPG;
+            const float mu = mean[((size_t)tile * G + g) * 32 + j], rs = rstd[((size_t)tile * G + g) * 32 + j];
+            const float ia = rs * gamma[ch], ib = __builtin_fmaf(-mu, ia, beta[ch]);
+            const float xh = (xs[k] - mu) * rs;
+            const float gi = __builtin_fmaf(xs[k], ia, ib) > 0.0f ? ds[k] * gamma[ch] : 0.0f;
+            r[k] = rs * (gi - s1[((size_t)tile * G + g) * 32 + j] * inv_n - xh * (s2[((size_t)tile * G + g) * 32 + j] * inv_n));
+        }
+        f32x4 out = {r[0], r[1], r[2], r[3]};
+        if (add) out = out + ((const f32x4*)add)[o];
+        ((f32x4*)dx)[o] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ChannelAttention backward (y = x * g, g = sigmoid(W2 relu(W0 mean_pos(x))), VQVAE_v2.py:213-228), one wave per tile.
+// dyA (+ dyB): gradient(s) wrt y.  dx = dy*g + dm/NP;  partial weight gradients summed over the tile's leaves:
+// pfc0[tile][R][C], pfc2[tile][C][R].
+// ------------------------------------------------------------------------------------------
+template <int C, int NP>
+__global__ __launch_bounds__(64) void se_bwd_k(const float* __restrict__ x, const float* __restrict__ dyA, const float* __restrict__ dyB,
+                                               const float* __restrict__ csum, const float* __restrict__ fc0, const float* __restrict__ fc2,
+                                               float* __restrict__ dx, float* __restrict__ pfc0, float* __restrict__ pfc2)
+{
+    constexpr int R = C / 4;
+    __shared__ float dgl[C][32], gl[C][32], dml[C][32];
+    const int tile = blockIdx.x, lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const size_t base = (size_t)tile * NP * (C / 4) * 32 + j;
+    for (int quad = h; quad < C / 4; quad += 2) {
+        f32x4 s = {0, 0, 0, 0};
+        for (int p = 0; p < NP; ++p) {
+            const size_t o = base + ((size_t)p * (C / 4) + quad) * 32;
+            f32x4 d = ((const f32x4*)dyA)[o];
+            if (dyB) d = d + ((const f32x4*)dyB)[o];
+            s = s + d * ((const f32x4*)x)[o];
+        }
+        dgl[4 * quad + 0][j] = s.x, dgl[4 * quad + 1][j] = s.y, dgl[4 * quad + 2][j] = s.z, dgl[4 * quad + 3][j] = s.w;
+    }
+    __syncthreads();
+    float hid[R], g[C];
+    const float* cs = csum + (size_t)tile * C * 32 + j;
+    se_hidden<C>(cs, fc0, hid);
+    se_gates<C>(hid, fc2, g);
+    float dh[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) dh[r] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float da = dgl[c][j] * (g[c] * (1.0f - g[c]));
+        if (h == 0) {
+            gl[c][j] = g[c];
+            dgl[c][j] = da;  // reused: da
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) dh[r] = __builtin_fmaf(fc2[c * R + r], da, dh[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) dh[r] = hid[r] > 0.0f ? dh[r] : 0.0f;
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        float dm = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dm = __builtin_fmaf(fc0[r * C + c], dh[r], dm);
+        if (h == 0) dml[c][j] = dm * (1.0f / (float)NP);
+        // weight-gradient partials: reduce over the 32 leaves (both lane halves hold the same values)
+        const float m = cs[c * 32] * (1.0f / (float)NP);
+        const float da = dgl[c][j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float v2 = da * hid[r], v0 = dh[r] * m;
+            for (int o = 16; o > 0; o >>= 1) {
+                v2 += __shfl_xor(v2, o, 64);
+                v0 += __shfl_xor(v0, o, 64);
+            }
+            if (lane == 0) {
+                pfc2[((size_t)tile * C + c) * R + r] = v2;
+                pfc0[((size_t)tile * R + r) * C + c] = v0;
+            }
+        }
+    }
+    __syncthreads();
+    for (int quad = h; quad < C / 4; quad += 2) {
+        const f32x4 g4 = {gl[4 * quad][j], gl[4 * quad + 1][j], gl[4 * quad + 2][j], gl[4 * quad + 3][j]};
+        const f32x4 m4 = {dml[4 * quad][j], dml[4 * quad + 1][j], dml[4 * quad + 2][j], dml[4 * quad + 3][j]};
+        for (int p = 0; p < NP; ++p) {
+            const size_t o = base + ((size_t)p * (C / 4) + quad) * 32;
+            f32x4 d = ((const f32x4*)dyA)[o];
+            if (dyB) d = d + ((const f32x4*)dyB)[o];
+            ((f32x4*)dx)[o] = d * g4 + m4;
+        }
+    }
+}
+
+// straight-through estimator + commitment loss (VQVAE_v2.py:146-150): dz = dq + cst * (z - q), cst = 2*commitment/(rows*128) over the
+// GLOBAL batch; zero for the padded leaves of the last tile.  All three tensors in the L4 layout [tile][64][32][32][4].
+__global__ __launch_bounds__(256) void st_grad_k(const float* __restrict__ dq, const float* __restrict__ z, const float* __restrict__ q, float* __restrict__ dz,
+                                                 float cst, int64_t n_leaves, int n_tiles)
+{
+    const int64_t total = (int64_t)n_tiles * 64 * 32 * 32;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t leaf = (t >> 16) * 32 + (t & 31);
+        f32x4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (leaf < n_leaves) r = ((const f32x4*)dq)[t] + (((const f32x4*)z)[t] - ((const f32x4*)q)[t]) * cst;
+        ((f32x4*)dz)[t] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Data gradient of the down conv (Conv3d 16->32, k4 s2 p1, VQVAE_v2.py:239): a transposed convolution 32ch@4^3 -> 16ch@8^3.
+// 16x16x4 MFMA: rows = 16 input channels of the forward conv, cols = 16 leaves, K = the 32 output channels (two float4 per
+// lane).  Input voxel P receives from tap k (per axis) iff (P + 1 - k) is even and o = (P + 1 - k)/2 lies in [0,4): at most two
+// taps per axis.  One wave per 16-leaf half tile walks the 512 voxels.
+// wfrag[((tap*2 + blk)*64 + lane)*4 + i] = W[16 blk + 4 (lane>>4) + i][lane & 15][tap]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void refrag_down_t_k(const float* __restrict__ W, float* __restrict__ dst)
+{
+    const int lane = threadIdx.x;
+    for (int t = blockIdx.x; t < 64 * 2; t += gridDim.x) {
+        const int tap = t >> 1, blk = t & 1;
+        f32x4 v;
+        float* o = (float*)&v;
+        for (int i = 0; i < 4; ++i) o[i] = W[((size_t)(16 * blk + 4 * (lane >> 4) + i) * 16 + (lane & 15)) * 64 + tap];
+        ((f32x4*)dst)[(size_t)t * 64 + lane] = v;
+    }
+}
+__global__ __launch_bounds__(256) void deconv_down_k(const float* __restrict__ dy /*L4 32ch@4^3*/, const float* __restrict__ wfrag, float* __restrict__ dx /*L4 16ch@8^3*/,
+                                                     int n_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const int half = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = half >> 1;
+    if (tile >= n_tiles) return;
+    const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
+    const f32x4* in4 = (const f32x4*)dy + (size_t)tile * 64 * 8 * 32 + jj;
+    f32x4* out4 = (f32x4*)dx + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+    const f32x4* wf = (const f32x4*)wfrag + lane;
+    for (int P = 0; P < 512; ++P) {
+        const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int a = 0; a < 2; ++a) {
+            const int kd = ((D + 1) & 1) + 2 * a, od = (D + 1 - kd) >> 1;
+            if (od < 0 || od > 3) continue;
+            for (int b = 0; b < 2; ++b) {
+                const int kh = ((H + 1) & 1) + 2 * b, oh = (H + 1 - kh) >> 1;
+                if (oh < 0 || oh > 3) continue;
+                for (int e = 0; e < 2; ++e) {
+                    const int kw = ((Wd + 1) & 1) + 2 * e, ow = (Wd + 1 - kw) >> 1;
+                    if (ow < 0 || ow > 3) continue;
+                    const int tap = (kd * 4 + kh) * 4 + kw, o = (od * 4 + oh) * 4 + ow;
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const f32x4 w = wf[(size_t)(tap * 2 + blk) * 64];
+                        const f32x4 v = in4[((size_t)o * 8 + 4 * blk + q4) * 32];
+                        acc = mfma16(w.x, v.x, acc);
+                        acc = mfma16(w.y, v.y, acc);
+                        acc = mfma16(w.z, v.z, acc);
+                        acc = mfma16(w.w, v.w, acc);
+                    }
+                }
+            }
+        }
+        out4[(size_t)P * 4 * 32] = acc;
+    }
+}
+
+// weight gradient of the first conv (1 -> 16, k3 p1 @8^3): part[tile][16*27] ([co*27 + tap]); 9 waves = (kd, kh), 3 kw each
+__global__ __launch_bounds__(576) void wgrad_first_k(const float* __restrict__ dy /*L4 16ch@8^3*/, const float* __restrict__ xt /*[tile][512][32]*/,
+                                                     float* __restrict__ part)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int kd = wave / 3, kh = wave % 3;
+    float acc[3][16];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[k][c] = 0.0f;
+    const f32x4* dy4 = (const f32x4*)dy + (size_t)tile * 512 * 4 * 32 + j;
+    const float* x = xt + (size_t)tile * 512 * 32 + j;
+    for (int P = 256 * h; P < 256 * h + 256; ++P) {
+        const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
+        const int d = D + kd - 1, hh = H + kh - 1;
+        if (d < 0 || d > 7 || hh < 0 || hh > 7) continue;
+        f32x4 g[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) g[qd] = dy4[((size_t)P * 4 + qd) * 32];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int xw = Wd + kw - 1;
+            if (xw < 0 || xw > 7) continue;
+            const float xv = x[(size_t)((d * 8 + hh) * 8 + xw) * 32];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                acc[kw][4 * qd + 0] = __builtin_fmaf(g[qd].x, xv, acc[kw][4 * qd + 0]);
+                acc[kw][4 * qd + 1] = __builtin_fmaf(g[qd].y, xv, acc[kw][4 * qd + 1]);
+                acc[kw][4 * qd + 2] = __builtin_fmaf(g[qd].z, xv, acc[kw][4 * qd + 2]);
+                acc[kw][4 * qd + 3] = __builtin_fmaf(g[qd].w, xv, acc[kw][4 * qd + 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = acc[kw][c];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) part[(size_t)tile * 432 + c * 27 + (kd * 3 + kh) * 3 + kw] = v;
+        }
+}

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
 // arithmetic as a plain tap-by-tap evaluation.  conv2 fuses the residual `x + 0.1*y`; conv1 emits the
 // GroupNorm(8,16) statistics of its output.
 // ------------------------------------------------------------------------------------------
-template <int NR, bool RESID, bool STATS>
+template <int NR, bool RESID, bool STATS, bool RAWIN = false>
 __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     static_assert(NR == 2 || NR == 4, "output rows per wave");
@@ -354,13 +354,15 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
     if (tile >= A.n_tiles) return;
     const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
     float ia[4], ib[4];
+    if (!RAWIN) {  // RAWIN: plain convolution of the input (data-gradient launches)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = 4 * q4 + i, g = c >> 1;
-        const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + jj];
-        const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + jj];
-        ia[i] = rstd * A.in_gamma[c];
-        ib[i] = __builtin_fmaf(-mean, ia[i], A.in_beta[c]);
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q4 + i, g = c >> 1;
+            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + jj];
+            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + jj];
+            ia[i] = rstd * A.in_gamma[c];
+            ib[i] = __builtin_fmaf(-mean, ia[i], A.in_beta[c]);
+        }
     }
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
         bool last;
         do {
 #pragma unroll
-            for (int iw = 0; iw < 8; ++iw) {  // first use of the rolling buffer: waits for the loads of the previous step
+            for (int iw = 0; iw < 8 && !RAWIN; ++iw) {  // first use of the rolling buffer: waits for the loads of the previous step
                 f32x4 v = xr[iw];
                 v.x = fmaxf(__builtin_fmaf(v.x, ia[0], ib[0]), 0.0f);
                 v.y = fmaxf(__builtin_fmaf(v.y, ia[1], ib[1]), 0.0f);

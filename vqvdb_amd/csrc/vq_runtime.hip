@@ -23,6 +23,7 @@
 #include "../../include/vqvdb_hip.h"
 #include "vq_kernels.h"
 #include "vq_train_kernels.h"
+#include "vq_grad_kernels.h"
 
 namespace {
 
@@ -113,6 +114,16 @@ struct vqhip_codec {
     float* tr_z = nullptr;
     uint8_t* tr_idx = nullptr;
     int64_t tr_leaves = 0;
+    // full training step (vq_train_full.inc)
+    std::vector<float> h_params;                                   // raw tensors, state_dict order
+    std::map<std::string, std::pair<int64_t, int64_t>> p_off;      // name -> (offset, count) in the flat parameter vector
+    float *ft_P = nullptr, *ft_M = nullptr, *ft_V = nullptr;       // parameters, AdamW moments (device, flat)
+    char* ft_ws = nullptr;                                         // training workspace (saved activations, gradients)
+    int64_t ft_tiles = 0;
+    char* ft_part = nullptr;                                       // partial-gradient scratch
+    size_t ft_part_bytes = 0;
+    bool full_training = false, keep_y1 = false;
+    float* z4_out = nullptr;   // set around encode_chunk by the training forward: latent also in the L4 layout
     char* tr_part = nullptr;   // per-(code, row segment) partial statistics
     size_t tr_part_bytes = 0;
     float* tr_recon = nullptr;  // reconstruction scratch of vqhip_train_eval_device
@@ -478,6 +489,22 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
     return upload_steps(c, "steps.tail", steps);
 }
 
+// the 44 trainable tensors in the reference's parameter order (model.parameters(), python/VQVAE_v2.py)
+const char* const kTrainable[] = {
+    "encoder.pre.0.weight", "encoder.pre.0.bias", "encoder.pre.1.weight", "encoder.pre.1.bias",
+    "encoder.pre.3.gn1.weight", "encoder.pre.3.gn1.bias", "encoder.pre.3.conv1.weight", "encoder.pre.3.conv1.bias",
+    "encoder.pre.3.gn2.weight", "encoder.pre.3.gn2.bias", "encoder.pre.3.conv2.weight", "encoder.pre.3.conv2.bias",
+    "encoder.down.weight", "encoder.down.bias",
+    "encoder.res_stack.0.gn1.weight", "encoder.res_stack.0.gn1.bias", "encoder.res_stack.0.conv1.weight", "encoder.res_stack.0.conv1.bias",
+    "encoder.res_stack.0.gn2.weight", "encoder.res_stack.0.gn2.bias", "encoder.res_stack.0.conv2.weight", "encoder.res_stack.0.conv2.bias",
+    "encoder.attn.fc.0.weight", "encoder.attn.fc.2.weight", "encoder.proj.weight", "encoder.proj.bias",
+    "decoder.stem.0.weight", "decoder.stem.0.bias", "decoder.stem.1.weight", "decoder.stem.1.bias",
+    "decoder.res_stack.0.gn1.weight", "decoder.res_stack.0.gn1.bias", "decoder.res_stack.0.conv1.weight", "decoder.res_stack.0.conv1.bias",
+    "decoder.res_stack.0.gn2.weight", "decoder.res_stack.0.gn2.bias", "decoder.res_stack.0.conv2.weight", "decoder.res_stack.0.conv2.bias",
+    "decoder.attn.fc.0.weight", "decoder.attn.fc.2.weight", "decoder.up_conv.weight", "decoder.up_conv.bias",
+    "decoder.final.weight", "decoder.final.bias",
+};
+
 int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
 {
     std::string err;
@@ -508,6 +535,14 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     NEED(dfw, "decoder.final.weight", 1, 32, 3, 3, 3) NEED(dfb, "decoder.final.bias", 1)
     NEED(cb, "quantizer.embedding", 256, 128)
 #undef NEED
+    // raw tensors in state_dict order, for the full training step (vq_train_full.inc): flat parameter vector + offsets
+    c->h_params.clear();
+    c->p_off.clear();
+    for (const char* tn : kTrainable) {
+        const PackTensor& t = pk.at(tn);
+        c->p_off[tn] = {(int64_t)c->h_params.size(), (int64_t)t.count};
+        c->h_params.insert(c->h_params.end(), t.data, t.data + t.count);
+    }
     int rc;
 #define UP(...)                                 \
     if ((rc = upload(c, __VA_ARGS__)) != VQHIP_OK) return rc;
@@ -672,7 +707,7 @@ void launch_latent_assign(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx
     LatentArgs A{};
     A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
     A.wproj = w["tr.wproj"], A.bproj = w["tr.bproj"], A.efrag = w["tr.efrag"], A.ee_frag = w["tr.ee"];
-    A.idx = d_idx, A.z = d_latent, A.n_leaves = n, A.n_tiles = nt;
+    A.idx = d_idx, A.z = d_latent, A.z4 = c->z4_out, A.n_leaves = n, A.n_tiles = nt;
     if (split <= 1 && nt >= 1024) L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<8>, dim3((nt + 7) / 8), dim3(512), LDS_LATENT, s, A); });
     else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2, split > 1 ? split : 1), dim3(128), LDS_LATENT, s, A); });
 }
@@ -764,7 +799,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
-        A.in = a["xt"], A.out = c->debug ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
+        A.in = a["xt"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
         L.run("enc_conv_first_stats", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
@@ -1196,6 +1231,11 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->tr_z) hipFree(c->tr_z);
     if (c->tr_idx) hipFree(c->tr_idx);
     if (c->tr_part) hipFree(c->tr_part);
+    if (c->ft_P) hipFree(c->ft_P);
+    if (c->ft_M) hipFree(c->ft_M);
+    if (c->ft_V) hipFree(c->ft_V);
+    if (c->ft_ws) hipFree(c->ft_ws);
+    if (c->ft_part) hipFree(c->ft_part);
     if (c->tr_recon) hipFree(c->tr_recon);
     if (c->tr_loss_part) hipFree(c->tr_loss_part);
     for (int i = 0; i < 2; ++i) {
@@ -1790,9 +1830,19 @@ int vqhip_debug_fetch(vqhip_codec* c, const char* name, int64_t n, float* out)
     auto it = c->act.find(name);
     if (it == c->act.end()) return fail(c, VQHIP_ERR_INVALID, std::string("debug_fetch: unknown activation '") + name + "'");
     const int C = c->act_shape[name].first, NP = c->act_shape[name].second;
-    if (C < 4 || n > c->ws_tiles * 32) return fail(c, VQHIP_ERR_INVALID, "debug_fetch: not an L4 activation or n too large");
+    if ((C != 1 && C < 4) || n > std::max(c->ws_tiles, c->ft_tiles) * 32) return fail(c, VQHIP_ERR_INVALID, "debug_fetch: not a tile activation or n too large");
+    if (C == 1) {  // [tile][NP][32]
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        const int64_t tl = (n + 31) / 32;
+        std::vector<float> raw1((size_t)tl * 32 * NP);
+        HIPCHK(c, hipMemcpy(raw1.data(), it->second, raw1.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t l = 0; l < n; ++l)
+            for (int p = 0; p < NP; ++p) out[(size_t)l * NP + p] = raw1[((size_t)(l / 32) * NP + p) * 32 + (l % 32)];
+        return VQHIP_OK;
+    }
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());
     const int64_t tiles = (n + 31) / 32;
     std::vector<float> raw((size_t)tiles * 32 * C * NP);
     HIPCHK(c, hipMemcpy(raw.data(), it->second, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -1837,3 +1887,5 @@ int vqhip_selftest_mfma(vqhip_codec* c, int64_t* mismatches)
 }
 
 }  // extern "C"
+
+#include "vq_train_full.inc"

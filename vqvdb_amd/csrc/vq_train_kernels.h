@@ -48,6 +48,7 @@ struct LatentArgs {
     const float* ee_frag;   // [(ct*2+q)*16 + r]
     uint8_t* idx;           // [n_leaves][64]
     float* z;               // flat [n_leaves*64][128]
+    float* z4;              // optional: the same latent in the L4 tile layout [tile][64][32][32][4] (full training step)
     int64_t n_leaves;
     int n_tiles;
 };
@@ -120,10 +121,11 @@ __global__ __launch_bounds__(NW * 64, 2) void latent_assign_k(LatentArgs A)
                 z[t][4 * g + 3] = z[t][4 * g + 3] + bias.w;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) zzp = __builtin_fmaf(z[t][4 * g + i], z[t][4 * g + i], zzp);
-                if (live) {  // channels 32t + 8g + 4q .. +3 of this leaf's row
+                {  // channels 32t + 8g + 4q .. +3 of this leaf's row
                     f32x4 v;
                     v.x = z[t][4 * g + 0], v.y = z[t][4 * g + 1], v.z = z[t][4 * g + 2], v.w = z[t][4 * g + 3];
-                    zrow[8 * t + 2 * g + q] = v;
+                    if (live) zrow[8 * t + 2 * g + q] = v;
+                    if (A.z4) ((f32x4*)A.z4)[(((size_t)tile * 64 + p) * 32 + 8 * t + 2 * g + q) * 32 + j] = v;
                 }
             }
         const float zzo = __shfl_xor(zzp, 32, 64);
