@@ -185,16 +185,28 @@ int vqhip_train_set_state(vqhip_codec* codec, const float* embedding, const floa
 int vqhip_train_commit(vqhip_codec* codec);
 
 /* ---- full training step (extension; SURVEY.md §8 f-2, stage 2; python/training.py:47-258) -------------------------
- * fp32 forward + backward + AdamW for the encoder / decoder weights, EMA for the codebook.  In progress: see DESIGN.md §6c
- * for what is wired.  Parameters live in one flat vector in the reference's parameter order (vqhip_fulltrain_param_count). */
+ * fp32 forward + backward + AdamW for the encoder / decoder weights and EMA for the codebook, data parallel like stage 1:
+ *   vqhip_fulltrain_fwdbwd_device   this rank's batch -> flat gradient vector + auxiliary sums (local)
+ *   [host: all-reduce(SUM) of both buffers over RCCL, vqvdb_amd/full_training.py]
+ *   vqhip_fulltrain_apply_device    AdamW step on every rank + EMA codebook update + rebuild of all weight-derived tables
+ * Loss = 0.8 mse + 0.2 l1 + vq_loss (training.py:147-155, fp32 instead of the reference's autocast), means over the GLOBAL
+ * batch of n_global_leaves, so summing the ranks' gradients gives the gradient of the global loss.  Parameters live in one flat
+ * vector in the reference's parameter order (model.parameters(); 995 905 floats).  Requires vqhip_fulltrain_begin (which also
+ * starts the EMA state of vqhip_train_begin unless it is already running). */
+#define VQHIP_FULLTRAIN_AUX_FLOATS (VQHIP_VQ_STATS_FLOATS + 3) /* VQ statistics | sum (recon-x)^2 | sum |recon-x| | voxels */
 int vqhip_fulltrain_begin(vqhip_codec* codec);
 int64_t vqhip_fulltrain_param_count(const vqhip_codec* codec);
 /* Training-mode forward only (test hook): every activation stays in the workspaces for vqhip_debug_fetch. */
 int vqhip_fulltrain_forward_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, void* hip_stream);
-/* Forward + backward of this rank's batch: gradients of loss = 0.8 mse + 0.2 l1 + vq_loss (means over n_global leaves) into
- * grads_dev (flat, parameter order).  The host all-reduces grads_dev across ranks before the optimizer step. */
 int vqhip_fulltrain_fwdbwd_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, int64_t n_global_leaves, float* grads_dev,
-                                  void* hip_stream);
+                                  float* aux_dev /* VQHIP_FULLTRAIN_AUX_FLOATS or NULL */, void* hip_stream);
+/* step counts from 1 (bias correction).  Reference hyper-parameters: lr 1e-4 (cosine schedule on the host), betas 0.9 / 0.999,
+ * eps 1e-8, weight_decay 1e-4 (training.py:104-108); EMA decay 0.95, eps 1e-4.  aux_dev NULL leaves the codebook untouched. */
+int vqhip_fulltrain_apply_device(vqhip_codec* codec, const float* grads_dev, const float* aux_dev, float lr, int64_t step, float beta1, float beta2,
+                                 float adam_eps, float weight_decay, float ema_decay, float ema_eps, void* hip_stream);
+/* host copies of the flat parameter vector (checkpoints, export to a weight pack); set also rebuilds the device tables */
+int vqhip_fulltrain_get_params(vqhip_codec* codec, float* params);
+int vqhip_fulltrain_set_params(vqhip_codec* codec, const float* params);
 
 /* ---- measurement hooks (bench.py / tests) ---- */
 

@@ -98,3 +98,60 @@ def test_encoder_gradients_match_autograd(fcodec, ref_grads, weights):
     assert _rel(fcodec.fetch("g16b", N, 16, 512), tape["e.y1"].grad.numpy().reshape(N, 16, 512)) < 1e-4
     bad = [(name, _rel(g, ref_grads["w"][name].grad.numpy())) for name, g in got.items() if name.startswith("encoder.")]
     assert all(e < TOL_GRAD for _, e in bad), [b for b in bad if b[1] >= TOL_GRAD]
+
+
+def test_three_optimizer_steps_match_torch(weights):
+    """AdamW + EMA codebook over three steps against the same loop in PyTorch (autograd of tests/torch_ref.py + its functional
+    AdamW + the EMA formula of VQVAE_v2.py:133-144), then the trained weights through the inference entry points."""
+    from oracle.oracle import Oracle
+    from vqvdb_amd.full_training import FullTrainer
+    torch.set_num_threads(16)
+    nb = 64
+    batches = [synth.make_leaves(nb, seed=7000 + s) for s in range(3)]
+    # ---- torch side ----
+    w = {k: torch.as_tensor(v).clone() for k, v in weights.items()}
+    params = {k: v for k, v in w.items() if not k.startswith("quantizer.")}
+    cs, avg, opt_state, ref_loss = torch.ones(256), w["quantizer.embedding"].clone(), {}, []
+    for step, xb in enumerate(batches, start=1):
+        for p in params.values():
+            p.requires_grad_(True)
+            p.grad = None
+        loss, pieces = torch_ref.training_loss(torch.as_tensor(xb).view(-1, 1, 8, 8, 8), w)
+        loss.backward()
+        ref_loss.append(float(loss.detach()))
+        with torch.no_grad():
+            flat = pieces["z"].detach().permute(0, 2, 3, 4, 1).reshape(-1, 128)
+            enc = torch.nn.functional.one_hot(pieces["idx"], 256).float()
+            cs = cs * 0.95 + (1 - 0.95) * enc.sum(0)
+            avg = avg * 0.95 + (1 - 0.95) * (enc.t() @ flat)
+            w["quantizer.embedding"] = avg / cs.clamp(min=1e-4)[:, None]
+            grads = {k: p.grad for k, p in params.items()}
+            for p in params.values():
+                p.requires_grad_(False)
+            torch_ref.adamw_step(params, grads, opt_state, lr=1e-4, step=step)
+    # ---- HIP side ----
+    c = HipCodec(weightpack.dumps(weights))
+    tr = FullTrainer(c)
+    got_loss = [tr.step(torch.from_numpy(xb).cuda())["loss"] for xb in batches]
+    sd = tr.state_dict()
+    for a, b in zip(got_loss, ref_loss):
+        assert abs(a - b) < 2e-5 * abs(b), (got_loss, ref_loss)
+    lr = 1e-4
+    for name, p in params.items():
+        diff = np.abs(sd[name] - p.numpy())
+        # Adam's first steps move every element by ~lr regardless of the gradient's size, so an element whose gradient is zero
+        # within rounding may differ by up to 2 lr per step; the bulk must agree far better than that
+        assert diff.max() <= 6.5 * lr and diff.mean() < 0.05 * lr, (name, float(diff.max()), float(diff.mean()))
+    assert _rel(sd["quantizer.embedding"], w["quantizer.embedding"].numpy()) < 1e-4
+    assert _rel(sd["quantizer.cluster_size"], cs.numpy()) < 1e-6
+    # ---- inference with the trained model: folded tables rebuilt from the new parameters ----
+    tr.finish()
+    w2 = {k: np.ascontiguousarray(v) for k, v in sd.items() if k in weights}
+    leaves = synth.make_leaves(100, seed=99)
+    o = Oracle(w2, [t[0] for t in synth.TENSORS])
+    idx = c.encode(leaves)
+    assert np.array_equal(idx, o.encode(leaves, threads=16))
+    assert np.array_equal(c.decode(idx).view(np.uint32), np.where(o.decode(idx, threads=16) == 0, 0.0, o.decode(idx, threads=16)).astype(np.float32).view(np.uint32))
+    fresh = HipCodec(weightpack.dumps(w2))
+    assert np.array_equal(fresh.encode(leaves), idx)
+    fresh.close(), c.close()

@@ -92,6 +92,7 @@ ABI_SYMBOLS = [
     "vqhip_train_begin", "vqhip_train_vq_stats_device", "vqhip_train_vq_update_device", "vqhip_train_get_state", "vqhip_train_set_state",
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
+    "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -155,7 +156,11 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_param_count.argtypes = [vp]
     lib.vqhip_fulltrain_param_count.restype = i64
     lib.vqhip_fulltrain_forward_device.argtypes = [vp, vp, i64, vp]
-    lib.vqhip_fulltrain_fwdbwd_device.argtypes = [vp, vp, i64, i64, vp, vp]
+    lib.vqhip_fulltrain_fwdbwd_device.argtypes = [vp, vp, i64, i64, vp, vp, vp]
+    cf = ctypes.c_float
+    lib.vqhip_fulltrain_apply_device.argtypes = [vp, vp, vp, cf, i64, cf, cf, cf, cf, cf, cf, vp]
+    lib.vqhip_fulltrain_get_params.argtypes = [vp, vp]
+    lib.vqhip_fulltrain_set_params.argtypes = [vp, vp]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
     lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
     lib.vqhip_debug_enable.argtypes = [vp, ci]
@@ -354,8 +359,24 @@ class HipCodec:
     def fulltrain_forward_device(self, leaves_ptr: int, n: int, stream: int = 0):
         self._check(self._lib.vqhip_fulltrain_forward_device(self._h, leaves_ptr, n, stream or None))
 
-    def fulltrain_fwdbwd_device(self, leaves_ptr: int, n: int, n_global: int, grads_ptr: int, stream: int = 0):
-        self._check(self._lib.vqhip_fulltrain_fwdbwd_device(self._h, leaves_ptr, n, n_global, grads_ptr, stream or None))
+    def fulltrain_fwdbwd_device(self, leaves_ptr: int, n: int, n_global: int, grads_ptr: int, aux_ptr: int = 0, stream: int = 0):
+        self._check(self._lib.vqhip_fulltrain_fwdbwd_device(self._h, leaves_ptr, n, n_global, grads_ptr, aux_ptr or None, stream or None))
+
+    def fulltrain_apply_device(self, grads_ptr: int, aux_ptr: int, lr: float, step: int, betas=(0.9, 0.999), adam_eps: float = 1e-8,
+                               weight_decay: float = 1e-4, ema_decay: float = 0.95, ema_eps: float = 1e-4, stream: int = 0):
+        self._check(self._lib.vqhip_fulltrain_apply_device(self._h, grads_ptr, aux_ptr or None, lr, step, betas[0], betas[1], adam_eps, weight_decay,
+                                                           ema_decay, ema_eps, stream or None))
+
+    def fulltrain_get_params(self) -> np.ndarray:
+        out = np.empty(self.fulltrain_param_count(), dtype=np.float32)
+        self._check(self._lib.vqhip_fulltrain_get_params(self._h, out.ctypes.data))
+        return out
+
+    def fulltrain_set_params(self, flat: np.ndarray):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        if flat.size != self.fulltrain_param_count():
+            raise ValueError("flat parameter vector has the wrong length")
+        self._check(self._lib.vqhip_fulltrain_set_params(self._h, flat.ctypes.data))
 
     def fetch(self, name: str, n: int, channels: int, positions: int) -> np.ndarray:
         """debug_fetch without the debug flag: any named workspace tensor as [n, channels, positions]."""

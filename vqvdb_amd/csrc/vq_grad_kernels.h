@@ -639,3 +639,19 @@ __global__ __launch_bounds__(576) void wgrad_first_k(const float* __restrict__ d
             if (lane == 0) part[(size_t)tile * 432 + c * 27 + (kd * 3 + kh) * 3 + kw] = v;
         }
 }
+
+// torch.optim.AdamW (decoupled weight decay) on the flat parameter vector; bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t)
+__global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                               float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2s)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * weight_decay);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+        p[i] = pi;
+    }
+}

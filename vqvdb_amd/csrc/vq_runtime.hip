@@ -122,7 +122,7 @@ struct vqhip_codec {
     int64_t ft_tiles = 0;
     char* ft_part = nullptr;                                       // partial-gradient scratch
     size_t ft_part_bytes = 0;
-    bool full_training = false, keep_y1 = false;
+    bool full_training = false, keep_y1 = false, weights_stale = false;
     float* z4_out = nullptr;   // set around encode_chunk by the training forward: latent also in the L4 layout
     char* tr_part = nullptr;   // per-(code, row segment) partial statistics
     size_t tr_part_bytes = 0;
@@ -486,7 +486,7 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
     int rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
-    return upload_steps(c, "steps.tail", steps);
+    return c->dw.count("steps.tail") ? VQHIP_OK : upload_steps(c, "steps.tail", steps);  // the schedule does not depend on the weights
 }
 
 // the 44 trainable tensors in the reference's parameter order (model.parameters(), python/VQVAE_v2.py)
@@ -1020,8 +1020,18 @@ int refresh_tables(vqhip_codec* c)
     std::vector<float> E(256 * 128);
     HIPCHK(c, hipDeviceSynchronize());  // the codebook may have been updated on a caller's stream
     HIPCHK(c, hipMemcpy(E.data(), c->dw["cb"], E.size() * sizeof(float), hipMemcpyDeviceToHost));
-    int rc = build_vq_fold(c, E.data());
-    if (rc) return rc;
+    int rc;
+    if (c->weights_stale) {
+        // full training changed the encoder / decoder weights: the device fragments were rebuilt after the optimizer step;
+        // what is folded on the host in fp64 (decoder tail, projection inside the VQ search) is rebuilt here from the parameters
+        HIPCHK(c, hipMemcpy(c->h_params.data(), c->ft_P, c->h_params.size() * sizeof(float), hipMemcpyDeviceToHost));
+        auto hp = [&](const char* n) { return c->h_params.data() + c->p_off.at(n).first; };
+        c->h_proj_w.assign(hp("encoder.proj.weight"), hp("encoder.proj.weight") + 128 * 32);
+        c->h_proj_b.assign(hp("encoder.proj.bias"), hp("encoder.proj.bias") + 128);
+        if ((rc = build_folded_tail(c, hp("decoder.up_conv.weight"), hp("decoder.up_conv.bias"), hp("decoder.final.weight"), hp("decoder.final.bias")))) return rc;
+        c->weights_stale = false;
+    }
+    if ((rc = build_vq_fold(c, E.data()))) return rc;
     hipLaunchKernelGGL(build_stem_lut_k, dim3(27 * 256), dim3(64), 0, c->stream, c->dw["ds.w"], c->dw["cb"], c->dw["ds.lut"]);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,112 @@
+"""Full VQ-VAE training step on the HIP backend — host side of SURVEY.md §8 f-2, stage 2 (python/training.py:47-258).
+
+Per step and rank:  forward + backward of the rank's batch -> flat gradient vector G and the auxiliary sums (HIP kernels)
+                    all_reduce(G, SUM), all_reduce(aux, SUM)          # RCCL over xGMI: 3.98 MB + 133 KB
+                    AdamW on the 995 905 parameters, EMA on the codebook, device tables rebuilt (HIP kernels)
+The loss is the reference's 0.8 mse + 0.2 l1 + vq_loss in fp32 (no autocast); gradients are those of the mean over the GLOBAL
+batch, so every rank applies the identical update and the replicas never diverge.  torch is used for device memory, streams,
+torch.distributed and the cosine learning-rate schedule only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from vqvdb_amd import synth
+from vqvdb_amd.codebook_training import STATS_FLOATS, metrics_from_stats
+
+AUX_FLOATS = STATS_FLOATS + 3
+TRAINABLE = [(name, shape) for name, shape, _ in synth.TENSORS if not name.startswith("quantizer.")]
+
+
+def flat_to_dict(flat: np.ndarray) -> dict:
+    """Flat parameter vector (the reference's parameter order) -> {state_dict name: array}."""
+    out, off = {}, 0
+    for name, shape in TRAINABLE:
+        n = int(np.prod(shape))
+        out[name] = flat[off:off + n].reshape(shape).copy()
+        off += n
+    if off != flat.size:
+        raise ValueError("flat parameter vector has the wrong length")
+    return out
+
+
+def dict_to_flat(params: dict) -> np.ndarray:
+    return np.concatenate([np.asarray(params[name], dtype=np.float32).reshape(-1) for name, _ in TRAINABLE])
+
+
+def cosine_lr(base_lr: float, step: int, t_max: int, eta_min: float = 0.0) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingLR (training.py:107-108) in closed form; `step` counts optimizer steps done."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * step / t_max)) / 2.0
+
+
+class FullTrainer:
+    """Drives vqhip_fulltrain_* for one rank.  `codec` is a vqvdb_amd.codec.HipCodec on this rank's device."""
+
+    def __init__(self, codec, lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 1e-4,
+                 commitment_cost: float = 0.25, ema_decay: float = 0.95, ema_eps: float = 1e-4, t_max: Optional[int] = None, group=None,
+                 device: str = "cuda"):
+        self.codec, self.group, self.device = codec, group, torch.device(device)
+        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        self.commitment_cost, self.ema_decay, self.ema_eps, self.t_max = commitment_cost, ema_decay, ema_eps, t_max
+        if abs(commitment_cost - 0.25) > 1e-12:
+            raise ValueError("the kernels fix commitment_cost = 0.25 (training.py:55)")
+        codec.fulltrain_begin()
+        self.grads = torch.zeros(codec.fulltrain_param_count(), dtype=torch.float32, device=self.device)
+        self.aux = torch.zeros(AUX_FLOATS, dtype=torch.float32, device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.steps_done = 0
+
+    def _world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def step(self, leaves: torch.Tensor, want_metrics: bool = True) -> Optional[dict]:
+        """One optimizer step on this rank's batch (float32, 512 values per leaf, resident on the device; every rank passes the
+        same number of leaves)."""
+        leaves = leaves.contiguous()
+        if leaves.dtype != torch.float32 or leaves.numel() % 512:
+            raise ValueError("leaves must be float32 with 512 values per leaf")
+        n = leaves.numel() // 512
+        world = self._world()
+        lr = self.lr if self.t_max is None else cosine_lr(self.lr, self.steps_done, self.t_max)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        out = None
+        with torch.cuda.stream(self.stream):
+            h = self.stream.cuda_stream
+            self.codec.fulltrain_fwdbwd_device(leaves.data_ptr(), n, n * world, self.grads.data_ptr(), self.aux.data_ptr(), stream=h)
+            if world > 1:
+                dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self.aux, op=dist.ReduceOp.SUM, group=self.group)
+            self.codec.fulltrain_apply_device(self.grads.data_ptr(), self.aux.data_ptr(), lr, self.steps_done + 1, self.betas, self.adam_eps,
+                                              self.weight_decay, self.ema_decay, self.ema_eps, stream=h)
+            if want_metrics:
+                aux = self.aux.cpu().numpy().astype(np.float64)
+                out = metrics_from_stats(aux[:STATS_FLOATS], self.commitment_cost)
+                sq, ab, vox = aux[STATS_FLOATS:]
+                out.update(recon_mse=float(sq / vox), recon_l1=float(ab / vox), lr=lr)
+                out["recon_error"] = 0.8 * out["recon_mse"] + 0.2 * out["recon_l1"]
+                out["loss"] = out["recon_error"] + out["vq_loss"]
+        leaves.record_stream(self.stream)
+        cur.wait_stream(self.stream)
+        self.steps_done += 1
+        return out
+
+    def state_dict(self) -> dict:
+        """Model state in the reference's state_dict naming (parameters + quantizer buffers)."""
+        sd = flat_to_dict(self.codec.fulltrain_get_params())
+        sd.update({f"quantizer.{k}": v for k, v in self.codec.train_get_state().items()})
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        self.codec.fulltrain_set_params(dict_to_flat(sd))
+        self.codec.train_set_state(embedding=sd["quantizer.embedding"], cluster_size=sd.get("quantizer.cluster_size"),
+                                   embed_avg=sd.get("quantizer.embed_avg"))
+
+    def finish(self):
+        """Rebuild what the inference path folds on the host (decoder tail, projection inside the VQ search, stem table)."""
+        self.codec.train_commit()
