@@ -391,9 +391,9 @@ class HipCodec:
         self._check(self._lib.vqhip_profile_enable(self._h, int(on)))
 
     def profile_read(self) -> list:
-        stats = (_KernelStat * 64)()
+        stats = (_KernelStat * 256)()
         cnt = ctypes.c_int()
-        self._check(self._lib.vqhip_profile_read(self._h, stats, 64, ctypes.byref(cnt)))
+        self._check(self._lib.vqhip_profile_read(self._h, stats, 256, ctypes.byref(cnt)))
         return [dict(name=s.name.decode(), launches=s.launches, total_ms=s.total_ms, flops_per_leaf=s.flops_per_leaf,
                      eff_flops_per_leaf=s.eff_flops_per_leaf, leaves=s.leaves) for s in stats[:cnt.value]]
 

@@ -206,6 +206,8 @@ __global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ d
                                                      float* __restrict__ part)
 {
     const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int np = 256 / gridDim.y;   // voxels per lane half and y-range
+    part += (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 865 - (size_t)tile * 865;
     const float* src = (wave < 4 ? upA : upB) + (size_t)tile * 64 * 32 * 128;
     float acc[27][4];
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ d
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[t][k] = 0.0f;
     float bsum = 0.0f;
-    for (int P = 256 * h; P < 256 * h + 256; ++P) {
+    for (int P = 256 * h + np * blockIdx.y; P < 256 * h + np * (blockIdx.y + 1); ++P) {
         const float dp = dpre[((size_t)tile * 512 + P) * 32 + j];
         bsum += dp;
         const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
@@ -283,18 +285,27 @@ struct WgradArgs {
 template <int CIN, int COUT, int NPI, int NPO, int INMODE, int GIN>
 __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void wgrad32_k(WgradArgs A)
 {
-    constexpr int CB = (COUT + 31) / 32, IB = (CIN + 31) / 32, NT = CB * IB * 64;
-    __shared__ float sdy[CB * 32][33];
-    __shared__ float sx[IB * 32][33];
-    for (int i = threadIdx.x; i < CB * 32 * 33; i += NT) (&sdy[0][0])[i] = 0.0f;
-    for (int i = threadIdx.x; i < IB * 32 * 33; i += NT) (&sx[0][0])[i] = 0.0f;
+    // CIN == 16 (the 8^3 layers): one wave, 16x16x4 MFMAs (K = 4 leaves), COUT/16 accumulators; otherwise one wave per
+    // 32 x 32 (co, ci) block on the 32x32x2 MFMA (K = 2 leaves)
+    constexpr bool SMALL = CIN == 16;
+    constexpr int CB = SMALL ? 1 : (COUT + 31) / 32, IB = SMALL ? 1 : (CIN + 31) / 32, NT = CB * IB * 64;
+    constexpr int ROWS_DY = SMALL ? COUT : CB * 32, ROWS_X = SMALL ? 16 : IB * 32;
+    __shared__ float sdy[ROWS_DY][33];
+    __shared__ float sx[ROWS_X][33];
+    for (int i = threadIdx.x; i < ROWS_DY * 33; i += NT) (&sdy[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < ROWS_X * 33; i += NT) (&sx[0][0])[i] = 0.0f;
     const int tap = blockIdx.x, grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
-    const int s0 = A.tap_start[tap], s1 = A.tap_start[tap + 1];
+    // the tap's (ip, po) pairs are cut into gridDim.z chunks (more workgroups for the small layers)
+    const int t_s0 = A.tap_start[tap], t_s1 = A.tap_start[tap + 1];
+    const int s0 = t_s0 + (int)((int64_t)(t_s1 - t_s0) * blockIdx.z / gridDim.z), s1 = t_s0 + (int)((int64_t)(t_s1 - t_s0) * (blockIdx.z + 1) / gridDim.z);
     const int t0 = grp * A.tiles_per_group, t1 = min(A.n_tiles, t0 + A.tiles_per_group);
     f32x16 acc;
+    f32x4 acc16[SMALL ? COUT / 16 : 1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < (SMALL ? COUT / 16 : 1); ++b) acc16[b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
     for (int tile = t0; tile < t1; ++tile) {
         for (int si = s0; si < s1; ++si) {
@@ -324,16 +335,34 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
                 }
             }
             __syncthreads();
+            if (SMALL) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
-                acc = mfma32(sdy[32 * cb + (lane & 31)][2 * m + (lane >> 5)], sx[32 * ib + (lane & 31)][2 * m + (lane >> 5)], acc);
+                for (int m = 0; m < 8; ++m) {
+                    const float bx = sx[lane & 15][4 * m + (lane >> 4)];
+#pragma unroll
+                    for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[16 * b + (lane & 15)][4 * m + (lane >> 4)], bx, acc16[b]);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    acc = mfma32(sdy[32 * cb + (lane & 31)][2 * m + (lane >> 5)], sx[32 * ib + (lane & 31)][2 * m + (lane >> 5)], acc);
+            }
         }
     }
-    float* dst = A.part + ((size_t)grp * A.KT + tap) * COUT * CIN;
+    float* dst = A.part + (((size_t)grp * gridDim.z + blockIdx.z) * A.KT + tap) * COUT * CIN;
+    if (SMALL) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = 32 * ib + (lane & 31);
-        if (co < COUT && ci < CIN) dst[(size_t)co * CIN + ci] = acc[r];
+        for (int b = 0; b < COUT / 16; ++b) {
+            const float v[4] = {acc16[b].x, acc16[b].y, acc16[b].z, acc16[b].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)(16 * b + 4 * (lane >> 4) + r) * CIN + (lane & 15)] = v[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = 32 * ib + (lane & 31);
+            if (co < COUT && ci < CIN) dst[(size_t)co * CIN + ci] = acc[r];
+        }
     }
 }
 // dW[(row0+co)*IC + ci][tap] = scale * sum_grp part[grp][tap][co][ci]
@@ -567,7 +596,8 @@ __global__ __launch_bounds__(256) void deconv_down_k(const float* __restrict__ d
     const f32x4* in4 = (const f32x4*)dy + (size_t)tile * 64 * 8 * 32 + jj;
     f32x4* out4 = (f32x4*)dx + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
     const f32x4* wf = (const f32x4*)wfrag + lane;
-    for (int P = 0; P < 512; ++P) {
+    const int P0 = (int)(blockIdx.y * 512 / gridDim.y), P1 = (int)((blockIdx.y + 1) * 512 / gridDim.y);
+    for (int P = P0; P < P1; ++P) {
         const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int a = 0; a < 2; ++a) {
