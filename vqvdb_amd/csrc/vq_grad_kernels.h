@@ -81,28 +81,45 @@ __global__ __launch_bounds__(64) void se_gate_k(const float* __restrict__ csum, 
     }
 }
 
-// pixel-shuffled view of the up_conv output (PixelShuffle3D(2), VQVAE_v2.py:172-187): channel c of the 32-channel 8^3 tensor at
-// voxel (D,H,W) is channel c*8 + (D&1)*4 + (H&1)*2 + (W&1) of the 256-channel 4^3 tensor at (D>>1,H>>1,W>>1).  The 256 channels
-// live in two 128-channel L4 tensors (up_conv runs as two 128-cout launches).
-__device__ __forceinline__ size_t ps_offset(int c, int D, int H, int W, int j)
+// PixelShuffle3D(2) (VQVAE_v2.py:172-187) as a copy between the two 128-channel up_conv tensors (L4, 4^3) and a 32-channel L4 tensor
+// at 8^3: channel c at voxel (D,H,W) <- channel c*8 + (D&1)*4 + (H&1)*2 + (W&1) at (D>>1,H>>1,W>>1).  One thread per destination
+// float4 (4 channels of one leaf and voxel); REVERSE = the backward direction (gradient of the shuffle = inverse copy).
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void pixshuf_k(float* __restrict__ upA, float* __restrict__ upB, float* __restrict__ ps, int n_tiles)
 {
-    const int ch = c * 8 + (D & 1) * 4 + (H & 1) * 2 + (W & 1);
-    const int pos = ((D >> 1) * 4 + (H >> 1)) * 4 + (W >> 1);
-    return (((size_t)pos * 32 + ((ch & 127) >> 2)) * 32 + j) * 4 + (ch & 3);  // within one tile of the half (ch >> 7)
+    const int64_t total = (int64_t)n_tiles * 512 * 8 * 32;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int j = t & 31, quad = (t >> 5) & 7, P = (t >> 8) & 511;
+        const int64_t tile = t >> 17;
+        const int D = P >> 6, H = (P >> 3) & 7, W = P & 7;
+        const int sub = (D & 1) * 4 + (H & 1) * 2 + (W & 1), pos = ((D >> 1) * 4 + (H >> 1)) * 4 + (W >> 1);
+        float v[4];
+        if (REVERSE) {
+            const f32x4 s4 = ((const f32x4*)ps)[t];
+            v[0] = s4.x, v[1] = s4.y, v[2] = s4.z, v[3] = s4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = (4 * quad + k) * 8 + sub;
+            float* src = (ch < 128 ? upA : upB) + ((((size_t)tile * 64 + pos) * 32 + ((ch & 127) >> 2)) * 32 + j) * 4 + (ch & 3);
+            if (REVERSE) *src = v[k];
+            else v[k] = *src;
+        }
+        if (!REVERSE) ((f32x4*)ps)[t] = (f32x4){v[0], v[1], v[2], v[3]};
+    }
 }
 
-// final conv 32 -> 1, k3 p1 @8^3 on the pixel-shuffled tensor (VQVAE_v2.py:269,275) and sigmoid.  VALU: 864 MAC per voxel.
-// block = 32 leaves x 8 voxels of one tile; grid (tile, 64).
-__global__ __launch_bounds__(256) void final_fwd_k(const float* __restrict__ upA, const float* __restrict__ upB, const float* __restrict__ Wf,
-                                                   const float* __restrict__ bf, float* __restrict__ pre, float* __restrict__ recon)
+// final conv 32 -> 1, k3 p1 @8^3 on the pixel-shuffled tensor (VQVAE_v2.py:269,275) and sigmoid.  VALU: 864 MAC per voxel,
+// one float4 load per 4 MACs.  block = 32 leaves x 8 voxels of one tile; grid (tile, 64).
+__global__ __launch_bounds__(256) void final_fwd_k(const float* __restrict__ ps, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                   float* __restrict__ pre, float* __restrict__ recon)
 {
     __shared__ float w[864];
     for (int i = threadIdx.x; i < 864; i += 256) w[i] = Wf[i];
     __syncthreads();
     const int tile = blockIdx.x, j = threadIdx.x & 31;
     const int P = blockIdx.y * 8 + (threadIdx.x >> 5), D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
-    const float* a = upA + (size_t)tile * 64 * 32 * 128;
-    const float* b = upB + (size_t)tile * 64 * 32 * 128;
+    const f32x4* src = (const f32x4*)ps + (size_t)tile * 512 * 8 * 32 + j;
     float acc = 0.0f;
     for (int kd = 0; kd < 3; ++kd) {
         const int d = D + kd - 1;
@@ -113,11 +130,14 @@ __global__ __launch_bounds__(256) void final_fwd_k(const float* __restrict__ upA
             for (int kw = 0; kw < 3; ++kw) {
                 const int x = Wd + kw - 1;
                 if (x < 0 || x > 7) continue;
-                const int tap = (kd * 3 + kh) * 3 + kw;
-#pragma unroll 8
-                for (int c = 0; c < 32; ++c) {
-                    const float v = (c < 16 ? a : b)[ps_offset(c, d, h, x, j)];
-                    acc = __builtin_fmaf(w[c * 27 + tap], v, acc);
+                const int tap = (kd * 3 + kh) * 3 + kw, Q = (d * 8 + h) * 8 + x;
+#pragma unroll
+                for (int quad = 0; quad < 8; ++quad) {
+                    const f32x4 v = src[((size_t)Q * 8 + quad) * 32];
+                    acc = __builtin_fmaf(w[(4 * quad + 0) * 27 + tap], v.x, acc);
+                    acc = __builtin_fmaf(w[(4 * quad + 1) * 27 + tap], v.y, acc);
+                    acc = __builtin_fmaf(w[(4 * quad + 2) * 27 + tap], v.z, acc);
+                    acc = __builtin_fmaf(w[(4 * quad + 3) * 27 + tap], v.w, acc);
                 }
             }
         }
@@ -176,9 +196,8 @@ __global__ __launch_bounds__(256) void loss_sums_k(const float* __restrict__ x, 
 // ------------------------------------------------------------------------------------------
 // final conv backward (32 -> 1, k3 p1 @8^3 over the pixel-shuffled tensor)
 // ------------------------------------------------------------------------------------------
-// data gradient, written straight into the up_conv-output layout (PixelShuffle3D backward is the same index map)
-__global__ __launch_bounds__(256) void final_bwd_data_k(const float* __restrict__ dpre, const float* __restrict__ Wf, float* __restrict__ dupA,
-                                                        float* __restrict__ dupB)
+// data gradient wrt the pixel-shuffled tensor (L4, 32 channels @8^3)
+__global__ __launch_bounds__(256) void final_bwd_data_k(const float* __restrict__ dpre, const float* __restrict__ Wf, float* __restrict__ dps)
 {
     __shared__ float w[864];
     for (int i = threadIdx.x; i < 864; i += 256) w[i] = Wf[i];
@@ -192,39 +211,45 @@ __global__ __launch_bounds__(256) void final_bwd_data_k(const float* __restrict_
         const int d = D - (t / 9 - 1), h = H - ((t / 3) % 3 - 1), x = Wd - (t % 3 - 1);
         g[t] = (d >= 0 && d < 8 && h >= 0 && h < 8 && x >= 0 && x < 8) ? dpre[((size_t)tile * 512 + (d * 8 + h) * 8 + x) * 32 + j] : 0.0f;
     }
-    float* a = dupA + (size_t)tile * 64 * 32 * 128;
-    float* b = dupB + (size_t)tile * 64 * 32 * 128;
-    for (int c = 0; c < 32; ++c) {
-        float s = 0.0f;
+    f32x4* dst = (f32x4*)dps + ((size_t)tile * 512 + P) * 8 * 32 + j;
+    for (int quad = 0; quad < 8; ++quad) {
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int t = 0; t < 27; ++t) s = __builtin_fmaf(w[c * 27 + t], g[t], s);
-        (c < 16 ? a : b)[ps_offset(c, D, H, Wd, j)] = s;
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < 27; ++t) s[k] = __builtin_fmaf(w[(4 * quad + k) * 27 + t], g[t], s[k]);
+        dst[(size_t)quad * 32] = (f32x4){s[0], s[1], s[2], s[3]};
     }
 }
-// weight + bias gradient partials per tile: part[tile][865] ([c*27+tap], last = bias).  8 waves, wave w owns channels 4w..4w+3.
-__global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ dpre, const float* __restrict__ upA, const float* __restrict__ upB,
-                                                     float* __restrict__ part)
+// weight + bias gradient partials: part[(tile*gridDim.y + y)][865] ([c*27+tap], last = bias).  8 waves, wave w owns channel quad w;
+// gridDim.y cuts each lane half's 256 voxels into ranges.
+__global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ dpre, const float* __restrict__ ps, float* __restrict__ part)
 {
     const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-    const int np = 256 / gridDim.y;   // voxels per lane half and y-range
-    part += (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 865 - (size_t)tile * 865;
-    const float* src = (wave < 4 ? upA : upB) + (size_t)tile * 64 * 32 * 128;
+    const int np = 256 / gridDim.y;
+    part += (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 865;
+    const f32x4* src = (const f32x4*)ps + (size_t)tile * 512 * 8 * 32 + wave * 32 + j;
     float acc[27][4];
 #pragma unroll
     for (int t = 0; t < 27; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[t][k] = 0.0f;
     float bsum = 0.0f;
-    for (int P = 256 * h + np * blockIdx.y; P < 256 * h + np * (blockIdx.y + 1); ++P) {
-        const float dp = dpre[((size_t)tile * 512 + P) * 32 + j];
-        bsum += dp;
-        const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
+    // input-voxel-major: one float4 of the pixel-shuffled tensor per voxel Q, the 27 output gradients that used it as scalars
+    for (int Q = 256 * h + np * blockIdx.y; Q < 256 * h + np * (blockIdx.y + 1); ++Q) {
+        const f32x4 v = src[(size_t)Q * 8 * 32];
+        const int D = Q >> 6, H = (Q >> 3) & 7, Wd = Q & 7;
+        const float* dp0 = dpre + (size_t)tile * 512 * 32 + j;
+        bsum += dp0[(size_t)Q * 32];
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
-            const int d = D + t / 9 - 1, hh = H + (t / 3) % 3 - 1, x = Wd + t % 3 - 1;
+            const int d = D - (t / 9 - 1), hh = H - ((t / 3) % 3 - 1), x = Wd - (t % 3 - 1);   // output voxel P = Q - off(t)
             if (d < 0 || d > 7 || hh < 0 || hh > 7 || x < 0 || x > 7) continue;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[t][k] = __builtin_fmaf(dp, src[ps_offset(4 * wave + k, d, hh, x, j)], acc[t][k]);
+            const float dp = dp0[(size_t)((d * 8 + hh) * 8 + x) * 32];
+            acc[t][0] = __builtin_fmaf(dp, v.x, acc[t][0]);
+            acc[t][1] = __builtin_fmaf(dp, v.y, acc[t][1]);
+            acc[t][2] = __builtin_fmaf(dp, v.z, acc[t][2]);
+            acc[t][3] = __builtin_fmaf(dp, v.w, acc[t][3]);
         }
     }
 #pragma unroll
@@ -233,11 +258,11 @@ __global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ d
         for (int k = 0; k < 4; ++k) {
             float v = acc[t][k];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) part[(size_t)tile * 865 + (4 * wave + k) * 27 + t] = v;
+            if (lane == 0) part[(4 * wave + k) * 27 + t] = v;
         }
     if (wave == 0) {
         for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o, 64);
-        if (lane == 0) part[(size_t)tile * 865 + 864] = bsum;
+        if (lane == 0) part[864] = bsum;
     }
 }
 // dst[i] = scale * sum over parts (ascending) of part[p][i]
