@@ -242,6 +242,34 @@ def main():
         except Exception as e:  # noqa: BLE001 — the training leg must never take the headline measurement down
             train = {"error": f"{type(e).__name__}: {e}"}
 
+    # Full training step (BASELINE configs[4]: fp32 VQ-VAE, AdamW on encoder/decoder, EMA codebook; global batch N x 2048):
+    # forward + backward + all-reduce of gradients (3.98 MB) and statistics (133 KB) + optimizer step.
+    full = None
+    if not args.no_train:
+        try:
+            from vqvdb_amd.full_training import FullTrainer
+            fcodec = HipCodec(weightpack.dumps(W), device_id=local)
+            ftr = FullTrainer(fcodec, device=str(device))
+            full = {"note": "one optimizer step = training-mode forward (unfolded decoder) + backward of every layer + all-reduce + AdamW + EMA "
+                            "codebook update + rebuild of the weight-derived tables, fp32; not the headline value",
+                    "collective": (f"all_reduce(SUM) of 995905 + 33284 fp32 over {world} rank(s), "
+                                   f"{'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()}") if dist else "none (1 rank)",
+                    "flop_per_leaf_nominal": 3 * (ENC_FLOP + DEC_FLOP)}
+            ksteps = max(2, min(args.steps, 6))
+            for per_rank in (2048, 8192):
+                x = leaves[0][:per_rank]
+                for _ in range(2):
+                    ftr.step(x, want_metrics=False)
+                t_ft = timed(lambda s: ftr.step(x, want_metrics=False), ksteps, dist, device)
+                last = ftr.step(x)
+                lps = world * ksteps * per_rank / t_ft
+                full[f"per_rank_batch_{per_rank}"] = {"leaves_per_s": round(lps, 1), "ms_per_step": round(t_ft / ksteps * 1e3, 4), "steps": ksteps,
+                                                       "loss": round(last["loss"], 6), "perplexity": round(last["perplexity"], 3),
+                                                       "frac_of_fp32_mfma_peak_nominal": round(lps / world * 3 * (ENC_FLOP + DEC_FLOP) / (PEAK_TF * 1e12), 4)}
+            fcodec.close()
+        except Exception as e:  # noqa: BLE001 — never take the headline measurement down
+            full = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         ek = profile_pass(codec, enc, min(args.steps, 4), device, "flops_per_leaf")
         dk = profile_pass(codec, dec, min(args.steps, 4), device, "flops_per_leaf")
@@ -289,6 +317,7 @@ def main():
             "parity_sample": parity,
             "host_path": host,
             "codebook_training": train,
+            "full_training": full,
             "small_batch": small,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
