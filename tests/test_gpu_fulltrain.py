@@ -196,3 +196,22 @@ if world > 1:
     assert np.array_equal(r0, r1)                                   # replicas stay bit-identical
     d = np.abs(one - r0)
     assert d.max() <= 6.5e-4 and d.mean() < 5e-6, (float(d.max()), float(d.mean()))   # Adam sign-step caveat as above
+
+
+def test_epoch_driver_full_mode(weights, tmp_path):
+    """python -m vqvdb_amd.train_codebook train --mode full: the reference loop's shape with AdamW + cosine schedule; the loss goes down
+    and the exported weight pack reproduces the trainer's model at inference."""
+    from oracle.oracle import Oracle
+    from vqvdb_amd import train_codebook
+    (tmp_path / "m.vqw").write_bytes(weightpack.dumps(weights))
+    out = train_codebook.main(["train", "--mode", "full", "--pack", str(tmp_path / "m.vqw"), "--epochs", "2", "--batch_size", "512",
+                               "--leaves_per_epoch", "8192", "--model_path", str(tmp_path / "ck" / "model.npz"), "--log_every", "4"])
+    h = out["history"]
+    assert len(h) == 2 and h[1]["train_loss"] < h[0]["train_loss"] and h[1]["val_loss"] < h[0]["val_loss"]
+    sd = np.load(tmp_path / "ck" / "model_final.npz")
+    assert "encoder.pre.0.weight" in sd.files and "quantizer.embed_avg" in sd.files
+    c = HipCodec(str(tmp_path / "ck" / "model_final.vqw"))
+    leaves = synth.make_leaves(50, seed=2)
+    w2 = {k: sd[k] for k in weights}
+    assert np.array_equal(c.encode(leaves), Oracle(w2, [t[0] for t in synth.TENSORS]).encode(leaves, threads=8))
+    c.close()

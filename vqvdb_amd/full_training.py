@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from vqvdb_amd import synth
-from vqvdb_amd.codebook_training import STATS_FLOATS, metrics_from_stats
+from vqvdb_amd.codebook_training import STATS_FLOATS, allreduce_stats, dead_code_reset, metrics_from_stats
 
 AUX_FLOATS = STATS_FLOATS + 3
 TRAINABLE = [(name, shape) for name, shape, _ in synth.TENSORS if not name.startswith("quantizer.")]
@@ -95,6 +95,42 @@ class FullTrainer:
         cur.wait_stream(self.stream)
         self.steps_done += 1
         return out
+
+    def evaluate(self, leaves: torch.Tensor, mse_weight: float = 0.8, l1_weight: float = 0.2) -> dict:
+        """Validation forward (training.py:183-199) with the current weights through the inference kernels: reconstruction MSE / L1,
+        vq_loss and perplexity over the GLOBAL batch; nothing is updated."""
+        leaves = leaves.contiguous()
+        n = leaves.numel() // 512
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            buf = torch.zeros(STATS_FLOATS + 3, dtype=torch.float32, device=self.device)
+            self.codec.train_eval_device(leaves.data_ptr(), n, buf.data_ptr(), buf[STATS_FLOATS:].data_ptr(), stream=self.stream.cuda_stream)
+            allreduce_stats(buf, self.group)
+            host = buf.cpu().numpy().astype(np.float64)
+        leaves.record_stream(self.stream)
+        cur.wait_stream(self.stream)
+        out = metrics_from_stats(host[:STATS_FLOATS], self.commitment_cost)
+        sq, ab, elems = host[STATS_FLOATS:]
+        out.update(recon_mse=float(sq / elems), recon_l1=float(ab / elems))
+        out["recon_error"] = mse_weight * out["recon_mse"] + l1_weight * out["recon_l1"]
+        return out
+
+    def reset_dead_codes(self, leaves: torch.Tensor, threshold: float = 1.0, generator=None) -> int:
+        """check_and_reset_dead_codes (VQVAE_v2.py:382-417) from the encoder outputs of `leaves` under the current weights."""
+        leaves = leaves.contiguous()
+        n = leaves.numel() // 512
+        z = torch.empty((n * 64, 128), dtype=torch.float32, device=self.device)
+        scratch = torch.zeros(STATS_FLOATS, dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self.codec.train_vq_stats_device(leaves.data_ptr(), n, scratch.data_ptr(), latent_ptr=z.data_ptr(), stream=self.stream.cuda_stream)
+        self.stream.synchronize()
+        st = {k: torch.from_numpy(v).to(self.device) for k, v in self.codec.train_get_state().items()}
+        k = dead_code_reset(st, z, threshold, generator, self.group)
+        if k:
+            self.codec.train_set_state(**{kk: v.cpu().numpy() for kk, v in st.items()})
+        return k
 
     def state_dict(self) -> dict:
         """Model state in the reference's state_dict naming (parameters + quantizer buffers)."""

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from vqvdb_amd.codebook_training import CodebookTrainer
+from vqvdb_amd.full_training import FullTrainer
 from vqvdb_amd.codec import HipCodec
 from vqvdb_amd.sharding import shard_range
 
@@ -73,9 +74,14 @@ def train(args) -> dict:
     log = (lambda *a: print(*a, flush=True)) if rank == 0 else (lambda *a: None)
 
     codec = HipCodec(args.pack, device_id=local)
-    trainer = CodebookTrainer(codec, commitment_cost=args.commitment_cost, decay=args.decay, eps=args.eps, device=str(device))
     leaves = load_leaves(args.data_dir, args.leaves_per_epoch * 5 // 4, args.seed)
     tr_ids, va_ids = split_train_val(len(leaves), args.seed)
+    full = args.mode == "full"
+    if full:   # AdamW(lr, wd 1e-4, betas 0.9/0.999) + CosineAnnealingLR(T_max = epochs * steps) like training.py:104-108
+        trainer = FullTrainer(codec, lr=args.lr, commitment_cost=args.commitment_cost, ema_decay=args.decay, ema_eps=args.eps,
+                              t_max=args.epochs * max(len(tr_ids) // (args.batch_size * world), 1), device=str(device))
+    else:
+        trainer = CodebookTrainer(codec, commitment_cost=args.commitment_cost, decay=args.decay, eps=args.eps, device=str(device))
     log(f"Dataset: {len(leaves)} leaves, train {len(tr_ids)}, val {len(va_ids)}; {world} rank(s) x batch {args.batch_size}")
     # this rank's shard of every global batch, resident in HBM (2 KiB per leaf)
     gb = args.batch_size * world
@@ -92,17 +98,23 @@ def train(args) -> dict:
         order = np.random.default_rng(args.seed + 1 + epoch).permutation(tr_ids)        # shuffle=True (training.py:87-94)
         t0 = time.perf_counter()
         tot_vq, last = 0.0, None
+        first_batch = None
         for step in range(steps_per_epoch):
             batch = d_all[torch.from_numpy(shard(order, step)).to(device)]
             want = (step % args.log_every == 0) or step == steps_per_epoch - 1
-            m = trainer.step(batch, keep_latent=(step == 0), want_metrics=want)
+            if full:
+                if step == 0:
+                    first_batch = batch
+                m = trainer.step(batch, want_metrics=want)
+            else:
+                m = trainer.step(batch, keep_latent=(step == 0), want_metrics=want)
             if m is not None:
                 last = m
                 tot_vq += m["vq_loss"]
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         if (epoch + 1) % DEAD_CODE_RESET_INTERVAL == 0:
-            n_dead = trainer.reset_dead_codes()
+            n_dead = trainer.reset_dead_codes(first_batch) if full else trainer.reset_dead_codes()
             if n_dead:
                 log(f"INFO: Resetting {n_dead} dead codes.")
         # validation (training.py:183-199): whole validation set in global batches, metrics averaged over batches
@@ -114,7 +126,7 @@ def train(args) -> dict:
             for k in val:
                 val[k] += mv[k] / n_val
         val_loss = val["recon_error"] + val["vq_loss"]
-        rec = {"epoch": epoch + 1, "train_vq_loss": last["vq_loss"], "perplexity": last["perplexity"], "codes_used": last["codes_used"],
+        rec = {"epoch": epoch + 1, "train_loss": last.get("loss"), "train_vq_loss": last["vq_loss"], "perplexity": last["perplexity"], "codes_used": last["codes_used"],
                "val_loss": val_loss, **{f"val_{k}": v for k, v in val.items()}, "leaves_per_s": steps_per_epoch * gb / dt, "epoch_s": dt}
         history.append(rec)
         log(f"Epoch {epoch + 1:02d}/{args.epochs} | Train VQ: {last['vq_loss']:.6f} | Val Loss: {val_loss:.6f} | Perplexity: {last['perplexity']:.2f} | "
@@ -126,7 +138,11 @@ def train(args) -> dict:
     trainer.finish()
     if rank == 0:
         root, ext = os.path.splitext(args.model_path)
-        np.savez(root + "_final" + (ext or ".npz"), epoch=args.epochs, **trainer.state_dict())
+        sd = trainer.state_dict()
+        np.savez(root + "_final" + (ext or ".npz"), epoch=args.epochs, **sd)
+        if full:   # the role of the reference's scripted-model export (training.py:254-258): an inference artefact for this backend
+            from vqvdb_amd import weightpack
+            weightpack.save(root + "_final.vqw", {k: v for k, v in sd.items() if k not in ("quantizer.cluster_size", "quantizer.embed_avg")})
     log("Training completed!")
     codec.close()
     return {"history": history, "best_val_loss": best_val, "steps_per_epoch": steps_per_epoch, "world": world}
@@ -137,6 +153,9 @@ def main(argv=None):
     sub = parser.add_subparsers(dest="command", required=True)
     p = sub.add_parser("train", help="Train the codebook (encoder/decoder frozen).")
     p.add_argument("--pack", required=True, help="VQWPACK1 weight pack (vqvdb_amd/weightpack.py)")
+    p.add_argument("--mode", choices=("codebook", "full"), default="codebook",
+                   help="codebook: EMA codebook only (encoder/decoder frozen); full: AdamW on every weight + EMA codebook (training.py)")
+    p.add_argument("--lr", type=float, default=1e-4, help="full mode: AdamW learning rate (training.py:51)")
     p.add_argument("--data_dir", type=str, default=None, help="Directory with .npy leaf arrays [N,8,8,8]; synthetic leaves if omitted.")
     p.add_argument("--epochs", type=int, default=30)                      # training.py:50
     p.add_argument("--batch_size", type=int, default=2048, help="leaves per rank per step (training.py:49)")
