@@ -111,3 +111,23 @@ def test_vqvdbfile_numpy_matches_cpp_writer(tmp_path):
         vqvdbfile.loads(b"OPENVDB" + raw[7:])
     empty = [vqvdbfile.Grid("e", np.zeros((0, 3), np.int32), np.zeros((0, 64), np.uint8))]
     assert len(vqvdbfile.loads(vqvdbfile.dumps(empty))[0].origins) == 0
+
+
+def test_full_training_host_helpers(weights):
+    """Flat parameter vector <-> state_dict (the reference's parameter order) and the closed-form cosine schedule."""
+    import math
+    import torch
+    from vqvdb_amd import full_training as ft
+    flat = ft.dict_to_flat(weights)
+    assert flat.size == 995905 and flat.dtype == np.float32
+    back = ft.flat_to_dict(flat)
+    assert list(back) == [n for n, _ in ft.TRAINABLE] and all(np.array_equal(back[k], weights[k]) for k in back)
+    assert "quantizer.embedding" not in back
+    with pytest.raises(ValueError):
+        ft.flat_to_dict(flat[:-1])
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50)
+    for step in range(50):
+        assert math.isclose(ft.cosine_lr(1e-4, step, 50), sch.get_last_lr()[0], rel_tol=1e-9, abs_tol=1e-15)
+        opt.step()
+        sch.step()
