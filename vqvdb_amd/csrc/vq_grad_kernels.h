@@ -315,10 +315,11 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     constexpr bool SMALL = CIN == 16;
     constexpr int CB = SMALL ? 1 : (COUT + 31) / 32, IB = SMALL ? 1 : (CIN + 31) / 32, NT = CB * IB * 64;
     constexpr int ROWS_DY = SMALL ? COUT : CB * 32, ROWS_X = SMALL ? 16 : IB * 32;
-    __shared__ float sdy[ROWS_DY][33];
-    __shared__ float sx[ROWS_X][33];
-    for (int i = threadIdx.x; i < ROWS_DY * 33; i += NT) (&sdy[0][0])[i] = 0.0f;
-    for (int i = threadIdx.x; i < ROWS_X * 33; i += NT) (&sx[0][0])[i] = 0.0f;
+    constexpr int NS = 1;   // position pairs staged per barrier (4 for the 16-channel layers was measured 2x SLOWER than 1)
+    __shared__ float sdy[NS * ROWS_DY][33];
+    __shared__ float sx[NS * ROWS_X][33];
+    for (int i = threadIdx.x; i < NS * ROWS_DY * 33; i += NT) (&sdy[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < NS * ROWS_X * 33; i += NT) (&sx[0][0])[i] = 0.0f;
     const int tap = blockIdx.x, grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
     // the tap's (ip, po) pairs are cut into gridDim.z chunks (more workgroups for the small layers)
@@ -333,16 +334,18 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     for (int b = 0; b < (SMALL ? COUT / 16 : 1); ++b) acc16[b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
     for (int tile = t0; tile < t1; ++tile) {
-        for (int si = s0; si < s1; ++si) {
-            const int2 e = A.wsteps[si];  // x = input position, y = output position
-            __syncthreads();              // previous step's MFMAs have read the blocks
-            for (int i = threadIdx.x; i < (COUT / 4) * 32; i += NT) {
-                const int quad = i >> 5, leaf = i & 31;
-                const f32x4 v = ((const f32x4*)A.dy)[(((size_t)tile * NPO + e.y) * (COUT / 4) + quad) * 32 + leaf];
-                sdy[4 * quad + 0][leaf] = v.x, sdy[4 * quad + 1][leaf] = v.y, sdy[4 * quad + 2][leaf] = v.z, sdy[4 * quad + 3][leaf] = v.w;
+        for (int si = s0; si < s1; si += NS) {
+            __syncthreads();              // previous iteration's MFMAs have read the blocks
+            for (int i = threadIdx.x; i < NS * (COUT / 4) * 32; i += NT) {
+                const int sub = i / ((COUT / 4) * 32), quad = (i >> 5) % (COUT / 4), leaf = i & 31;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};   // a short last batch contributes zeros
+                if (si + sub < s1) v = ((const f32x4*)A.dy)[(((size_t)tile * NPO + A.wsteps[si + sub].y) * (COUT / 4) + quad) * 32 + leaf];
+                float* d = &sdy[sub * ROWS_DY + 4 * quad][leaf];
+                d[0] = v.x, d[33] = v.y, d[66] = v.z, d[99] = v.w;
             }
-            for (int i = threadIdx.x; i < (CIN / 4) * 32; i += NT) {
-                const int quad = i >> 5, leaf = i & 31;
+            for (int i = threadIdx.x; i < NS * (CIN / 4) * 32; i += NT) {
+                const int sub = i / ((CIN / 4) * 32), quad = (i >> 5) % (CIN / 4), leaf = i & 31;
+                const int2 e = A.wsteps[si + sub < s1 ? si + sub : s1 - 1];  // x = input position, y = output position
                 const f32x4 v = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + quad) * 32 + leaf];
                 float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -356,17 +359,20 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
                     } else if (INMODE == 2) {
                         o[k] = o[k] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
                     }
-                    sx[ch][leaf] = o[k];
+                    sx[sub * ROWS_X + ch][leaf] = o[k];
                 }
             }
             __syncthreads();
             if (SMALL) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const float bx = sx[lane & 15][4 * m + (lane >> 4)];
+                for (int sub = 0; sub < NS; ++sub)
 #pragma unroll
-                    for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[16 * b + (lane & 15)][4 * m + (lane >> 4)], bx, acc16[b]);
-                }
+                    for (int m = 0; m < 8; ++m) {
+                        const float bx = sx[sub * ROWS_X + (lane & 15)][4 * m + (lane >> 4)];
+#pragma unroll
+                        for (int b = 0; b < COUT / 16; ++b)
+                            acc16[b] = mfma16(sdy[sub * ROWS_DY + 16 * b + (lane & 15)][4 * m + (lane >> 4)], bx, acc16[b]);
+                    }
             } else {
 #pragma unroll
                 for (int m = 0; m < 16; ++m)
@@ -506,18 +512,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_k(const float* __restrict__ 
 // pfc0[tile][R][C], pfc2[tile][C][R].
 // ------------------------------------------------------------------------------------------
 template <int C, int NP>
-__global__ __launch_bounds__(64) void se_bwd_k(const float* __restrict__ x, const float* __restrict__ dyA, const float* __restrict__ dyB,
-                                               const float* __restrict__ csum, const float* __restrict__ fc0, const float* __restrict__ fc2,
-                                               float* __restrict__ dx, float* __restrict__ pfc0, float* __restrict__ pfc2)
+__global__ __launch_bounds__(64 * C / 8) void se_bwd_k(const float* __restrict__ x, const float* __restrict__ dyA, const float* __restrict__ dyB,
+                                                       const float* __restrict__ csum, const float* __restrict__ fc0, const float* __restrict__ fc2,
+                                                       float* __restrict__ dx, float* __restrict__ pfc0, float* __restrict__ pfc2)
 {
+    // C/8 waves; wave w owns channel quads 2w, 2w+1 (lane half h -> quad 2w+h) in the position sweeps; wave 0 does the per-leaf MLP
     constexpr int R = C / 4;
-    __shared__ float dgl[C][32], gl[C][32], dml[C][32];
-    const int tile = blockIdx.x, lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const size_t base = (size_t)tile * NP * (C / 4) * 32 + j;
-    for (int quad = h; quad < C / 4; quad += 2) {
+    __shared__ float dgl[C][32], gl[C][32], dml[C][32], hl[R][32], dhl[R][32];
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int quad = 2 * wave + h;
+    const size_t base = (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
+    {
         f32x4 s = {0, 0, 0, 0};
+#pragma unroll 4
         for (int p = 0; p < NP; ++p) {
-            const size_t o = base + ((size_t)p * (C / 4) + quad) * 32;
+            const size_t o = base + (size_t)p * (C / 4) * 32;
             f32x4 d = ((const f32x4*)dyA)[o];
             if (dyB) d = d + ((const f32x4*)dyB)[o];
             s = s + d * ((const f32x4*)x)[o];
@@ -525,52 +534,56 @@ __global__ __launch_bounds__(64) void se_bwd_k(const float* __restrict__ x, cons
         dgl[4 * quad + 0][j] = s.x, dgl[4 * quad + 1][j] = s.y, dgl[4 * quad + 2][j] = s.z, dgl[4 * quad + 3][j] = s.w;
     }
     __syncthreads();
-    float hid[R], g[C];
     const float* cs = csum + (size_t)tile * C * 32 + j;
-    se_hidden<C>(cs, fc0, hid);
-    se_gates<C>(hid, fc2, g);
-    float dh[R];
+    if (wave == 0) {
+        float hid[R], dh[R];
+        se_hidden<C>(cs, fc0, hid);
 #pragma unroll
-    for (int r = 0; r < R; ++r) dh[r] = 0.0f;
-    for (int c = 0; c < C; ++c) {
-        const float da = dgl[c][j] * (g[c] * (1.0f - g[c]));
-        if (h == 0) {
-            gl[c][j] = g[c];
-            dgl[c][j] = da;  // reused: da
+        for (int r = 0; r < R; ++r) dh[r] = 0.0f;
+        for (int c = 0; c < C; ++c) {   // gate, da = dg * g (1-g), dh += W2^T da
+            float a = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) a = __builtin_fmaf(fc2[c * R + r], hid[r], a);
+            const float gg = vq_sigmoid(a);
+            const float da = dgl[c][j] * (gg * (1.0f - gg));
+#pragma unroll
+            for (int r = 0; r < R; ++r) dh[r] = __builtin_fmaf(fc2[c * R + r], da, dh[r]);
+            if (h == 0) {
+                gl[c][j] = gg;
+                dgl[c][j] = da;   // reused: da
+            }
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) dh[r] = __builtin_fmaf(fc2[c * R + r], da, dh[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) dh[r] = hid[r] > 0.0f ? dh[r] : 0.0f;
-    __syncthreads();
-    for (int c = 0; c < C; ++c) {
-        float dm = 0.0f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) dm = __builtin_fmaf(fc0[r * C + c], dh[r], dm);
-        if (h == 0) dml[c][j] = dm * (1.0f / (float)NP);
-        // weight-gradient partials: reduce over the 32 leaves (both lane halves hold the same values)
-        const float m = cs[c * 32] * (1.0f / (float)NP);
-        const float da = dgl[c][j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float v2 = da * hid[r], v0 = dh[r] * m;
-            for (int o = 16; o > 0; o >>= 1) {
-                v2 += __shfl_xor(v2, o, 64);
-                v0 += __shfl_xor(v0, o, 64);
-            }
-            if (lane == 0) {
-                pfc2[((size_t)tile * C + c) * R + r] = v2;
-                pfc0[((size_t)tile * R + r) * C + c] = v0;
-            }
+            dh[r] = hid[r] > 0.0f ? dh[r] : 0.0f;
+            if (h == 0) hl[r][j] = hid[r], dhl[r][j] = dh[r];
+        }
+        for (int c = h; c < C; c += 2) {   // dm = W0^T dh, two channels per pass (one per lane half)
+            float dm = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dm = __builtin_fmaf(fc0[r * C + c], dh[r], dm);
+            dml[c][j] = dm * (1.0f / (float)NP);
         }
     }
     __syncthreads();
-    for (int quad = h; quad < C / 4; quad += 2) {
+    // FC weight-gradient partials, summed over the tile's 32 leaves: thread t owns entries t, t + blockDim, ...
+    for (int e = threadIdx.x; e < C * R; e += 64 * C / 8) {
+        const int c2 = e / R, r2 = e % R;      // pfc2[c][r] = sum_j da[c][j] h[r][j]
+        const int r0 = e / C, c0 = e % C;      // pfc0[r][c] = sum_j dh[r][j] m[c][j]
+        float v2 = 0.0f, v0 = 0.0f;
+        for (int jj = 0; jj < 32; ++jj) {
+            v2 = __builtin_fmaf(dgl[c2][jj], hl[r2][jj], v2);
+            v0 = __builtin_fmaf(dhl[r0][jj], csum[((size_t)tile * C + c0) * 32 + jj] * (1.0f / (float)NP), v0);
+        }
+        pfc2[(size_t)tile * C * R + e] = v2;
+        pfc0[(size_t)tile * C * R + e] = v0;
+    }
+    {
         const f32x4 g4 = {gl[4 * quad][j], gl[4 * quad + 1][j], gl[4 * quad + 2][j], gl[4 * quad + 3][j]};
         const f32x4 m4 = {dml[4 * quad][j], dml[4 * quad + 1][j], dml[4 * quad + 2][j], dml[4 * quad + 3][j]};
+#pragma unroll 4
         for (int p = 0; p < NP; ++p) {
-            const size_t o = base + ((size_t)p * (C / 4) + quad) * 32;
+            const size_t o = base + (size_t)p * (C / 4) * 32;
             f32x4 d = ((const f32x4*)dyA)[o];
             if (dyB) d = d + ((const f32x4*)dyB)[o];
             ((f32x4*)dx)[o] = d * g4 + m4;
