@@ -274,15 +274,21 @@ __global__ __launch_bounds__(256) void parts_reduce_k(const float* __restrict__ 
     for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + i];
     dst[i] = scale * s;
 }
-// dst[c] = scale * sum over tiles and leaves of part[tile][c][32]  (bias / GroupNorm-affine gradients from per-(tile,channel,leaf) sums)
-__global__ __launch_bounds__(64) void chan_reduce_k(const float* __restrict__ part, int n_tiles, int C, float* __restrict__ dst, float scale)
+// dst[c] = scale * sum over tiles and leaves of part[tile][c][32]  (bias / GroupNorm-affine gradients from per-(tile,channel,leaf) sums).
+// One 256-thread block per channel: thread t walks tiles t>>5, t>>5 + 8, ... for leaf t&31, then a fixed LDS tree (deterministic).
+__global__ __launch_bounds__(256) void chan_reduce_k(const float* __restrict__ part, int n_tiles, int C, float* __restrict__ dst, float scale)
 {
-    const int c = blockIdx.x, lane = threadIdx.x;
+    __shared__ float red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     float s = 0.0f;
-    for (int t = 0; t < n_tiles; ++t)
-        if (lane < 32) s += part[((size_t)t * C + c) * 32 + lane];
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) dst[c] = scale * s;
+    for (int tile = t >> 5; tile < n_tiles; tile += 8) s += part[((size_t)tile * C + c) * 32 + (t & 31)];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) dst[c] = scale * red[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -436,8 +442,11 @@ __global__ __launch_bounds__(64 * C / 8) void gn_bwd_sums_k(const float* __restr
     }
     const size_t base = (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+    // gridDim.y position ranges per tile; partial sums are indexed by (tile * gridDim.y + blockIdx.y) and added up by the consumers
+    const int p0 = (int)(blockIdx.y * NP / gridDim.y), p1 = (int)((blockIdx.y + 1) * NP / gridDim.y);
+    const size_t pt = (size_t)tile * gridDim.y + blockIdx.y;
 #pragma unroll 4
-    for (int p = 0; p < NP; ++p) {
+    for (int p = p0; p < p1; ++p) {
         const f32x4 xv = ((const f32x4*)x)[base + (size_t)p * (C / 4) * 32];
         const f32x4 dv = ((const f32x4*)da)[base + (size_t)p * (C / 4) * 32];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -454,14 +463,14 @@ __global__ __launch_bounds__(64 * C / 8) void gn_bwd_sums_k(const float* __restr
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        dgam[((size_t)tile * C + 4 * quad + k) * 32 + j] = dg[k];
-        dbet[((size_t)tile * C + 4 * quad + k) * 32 + j] = db[k];
+        dgam[(pt * C + 4 * quad + k) * 32 + j] = dg[k];
+        dbet[(pt * C + 4 * quad + k) * 32 + j] = db[k];
     }
     if (CPG == 2) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            s1[((size_t)tile * G + 2 * quad + k) * 32 + j] = a1[2 * k] + a1[2 * k + 1];
-            s2[((size_t)tile * G + 2 * quad + k) * 32 + j] = a2[2 * k] + a2[2 * k + 1];
+            s1[(pt * G + 2 * quad + k) * 32 + j] = a1[2 * k] + a1[2 * k + 1];
+            s2[(pt * G + 2 * quad + k) * 32 + j] = a2[2 * k] + a2[2 * k + 1];
         }
     } else {
         float t1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), t2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
@@ -471,15 +480,30 @@ __global__ __launch_bounds__(64 * C / 8) void gn_bwd_sums_k(const float* __restr
         }
         if (CPG == 4 || (lane >> 5) == 0) {
             const int g = CPG == 4 ? quad : quad >> 1;
-            s1[((size_t)tile * G + g) * 32 + j] = t1;
-            s2[((size_t)tile * G + g) * 32 + j] = t2;
+            s1[(pt * G + g) * 32 + j] = t1;
+            s2[(pt * G + g) * 32 + j] = t2;
         }
     }
+}
+// out[tile][i] = sum over the n_split position ranges of part[tile][range][i]   (i over G*32 values per tile)
+__global__ __launch_bounds__(256) void gn_bwd_combine_k(const float* __restrict__ p1, const float* __restrict__ p2, int n_split, int per_tile, int n_tiles,
+                                                        float* __restrict__ o1, float* __restrict__ o2)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles * per_tile) return;
+    const int tile = t / per_tile, i = t % per_tile;
+    float a = 0.0f, b = 0.0f;
+    for (int sp = 0; sp < n_split; ++sp) {
+        a += p1[((size_t)tile * n_split + sp) * per_tile + i];
+        b += p2[((size_t)tile * n_split + sp) * per_tile + i];
+    }
+    o1[t] = a;
+    o2[t] = b;
 }
 template <int C, int NP, int CPG>
 __global__ __launch_bounds__(256) void gn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ da, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ add,
+                                                      const float* __restrict__ s1, const float* __restrict__ s2, int n_split, const float* __restrict__ add,
                                                       float* __restrict__ dx)
 {
     constexpr int G = C / CPG;
@@ -498,7 +522,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_k(const float* __restrict__ 
             const float ia = rs * gamma[ch], ib = __builtin_fmaf(-mu, ia, beta[ch]);
             const float xh = (xs[k] - mu) * rs;
             const float gi = __builtin_fmaf(xs[k], ia, ib) > 0.0f ? ds[k] * gamma[ch] : 0.0f;
-            r[k] = rs * (gi - s1[((size_t)tile * G + g) * 32 + j] * inv_n - xh * (s2[((size_t)tile * G + g) * 32 + j] * inv_n));
+            float t1 = 0.0f, t2 = 0.0f;
+            for (int sp = 0; sp < n_split; ++sp) {
+                t1 += s1[(((size_t)tile * n_split + sp) * G + g) * 32 + j];
+                t2 += s2[(((size_t)tile * n_split + sp) * G + g) * 32 + j];
+            }
+            r[k] = rs * (gi - t1 * inv_n - xh * (t2 * inv_n));
         }
         f32x4 out = {r[0], r[1], r[2], r[3]};
         if (add) out = out + ((const f32x4*)add)[o];
