@@ -10,7 +10,7 @@ import sys
 
 LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the library's profiler)
     (r"conv_first_k<0>", "enc_conv_first_stats"), (r"conv_first_k<1>", "enc_conv_first_gn"),
-    (r"conv8_c16_k<4, false, true>", "enc_res16_conv1"), (r"conv8_c16_k<4, true, false>", "enc_res16_conv2"),
+    (r"conv8_c16_k<4, false, true, false>", "enc_res16_conv1"), (r"conv8_c16_k<4, true, false, false>", "enc_res16_conv2"),
     (r"conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 8,", "enc_down"),
     (r"conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, false", "enc_res32_conv1"),
     (r"conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, true", "enc_res32_conv2"),
@@ -23,11 +23,15 @@ LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the lib
 
 
 def read(path, counter):
+    """Per launch name: the average counter value over the launches with the LARGEST grid of that kernel (the 65536-leaf launches of the
+    throughput legs; the same kernels also run at small batches and with gridDim.y > 1)."""
     db = sqlite3.connect(path)
-    out = {}
-    for name, avg in db.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
+    out, best = {}, {}
+    for name, grid, avg in db.execute("select kernel_name, grid_size, avg(value) from counters_collection where counter_name=? group by kernel_name, grid_size",
+                                      (counter,)):
         for rx, launch in LAUNCH:
-            if re.search(rx, name) and not name.startswith("build_"):
+            if re.search(rx, name) and not name.startswith("build_") and grid > best.get(launch, -1):
+                best[launch] = grid
                 out[launch] = avg * 1024.0
     return out
 

@@ -19,11 +19,12 @@ def short(name):
 
 
 def pmc(path, counter):
+    """(kernel, grid) -> (launches, average counter value)"""
     db = sqlite3.connect(path)
     out = {}
-    for name, n, avg in db.execute(
-            "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
-        out[short(name)] = (n, avg)
+    for name, grid, n, avg in db.execute(
+            "select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name, grid_size", (counter,)):
+        out[(short(name), grid)] = (n, avg)
     return out
 
 
@@ -46,8 +47,8 @@ def main():
         k = short(name)
         if "at::native" in k or "rocclr" in k:
             continue
-        fm = f.get(k, (0, None))[1]
-        wm = w.get(k, (0, None))[1]
+        fm = f.get((k, grid), (0, None))[1]
+        wm = w.get((k, grid), (0, None))[1]
         print(f"{k:90s} {n:5d} {avg / 1e3:10.1f} {100 * s / tot:6.2f} {vg:5d} {ag:5d} {lds:7d} {scr:4d} {wg:4d} {grid:8d} "
               f"{(fm / 1024 if fm is not None else float('nan')):9.1f} {(fm / 512 if fm is not None else float('nan')):11.1f} {(wm / 1024 if wm is not None else float('nan')):9.1f}")
 
