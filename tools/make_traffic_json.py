@@ -27,8 +27,10 @@ def read(path, counter):
     throughput legs; the same kernels also run at small batches and with gridDim.y > 1)."""
     db = sqlite3.connect(path)
     out, best = {}, {}
-    for name, grid, avg in db.execute("select kernel_name, grid_size, avg(value) from counters_collection where counter_name=? group by kernel_name, grid_size",
-                                      (counter,)):
+    for name, grid, gy, avg in db.execute("select kernel_name, grid_size_x, grid_size_y, avg(value) from counters_collection where counter_name=? "
+                                          "group by kernel_name, grid_size_x, grid_size_y", (counter,)):
+        if gy != 1:   # position-split launches (small batches)
+            continue
         for rx, launch in LAUNCH:
             if re.search(rx, name) and not name.startswith("build_") and grid > best.get(launch, -1):
                 best[launch] = grid
