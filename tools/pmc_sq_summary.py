@@ -8,13 +8,17 @@ import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-rows = db.execute("select kernel_name, counter_name, avg(value), avg(end-start) from counters_collection group by kernel_name, counter_name").fetchall()
-d = {}
-for k, c, v, dur in rows:
+rows = db.execute("select kernel_name, grid_size_x, grid_size_y, counter_name, avg(value), avg(end-start) from counters_collection "
+                  "group by kernel_name, grid_size_x, grid_size_y, counter_name").fetchall()
+d, best = {}, {}
+for k, gx, gy, c, v, dur in rows:   # per kernel keep the unsplit launches with the largest grid (the 65536-leaf ones)
     k = re.sub(r"\(.*", "", k).replace("void ", "")
-    if "at::" in k or "rocclr" in k:
+    if "at::" in k or "rocclr" in k or gy != 1 or gx < best.get(k, 0):
         continue
-    d.setdefault(k, {})[c] = v
+    if gx > best.get(k, 0):
+        best[k] = gx
+        d[k] = {}
+    d[k][c] = v
     d[k]["dur"] = dur
 print(f"{'kernel':78s} {'avg_us':>9s} {'clk_GHz':>8s} {'mfma_util':>9s} {'wait_inst':>9s} {'wait_any':>9s} {'active':>7s}")
 for k, v in sorted(d.items(), key=lambda kv: -kv[1]["dur"]):
