@@ -215,3 +215,16 @@ def test_epoch_driver_full_mode(weights, tmp_path):
     w2 = {k: sd[k] for k in weights}
     assert np.array_equal(c.encode(leaves), Oracle(w2, [t[0] for t in synth.TENSORS]).encode(leaves, threads=8))
     c.close()
+
+
+def test_gradients_do_not_depend_on_the_launch_path(weights):
+    """The training forward reuses the inference encoder kernels: one-wave-per-tile launches (large batches) and position-split
+    launches (small batches) must give the same gradients; so must a batch that straddles tiles differently."""
+    x = synth.make_leaves(96, seed=6100)
+    a, b = HipCodec(weightpack.dumps(weights)), HipCodec(weightpack.dumps(weights))
+    a.fulltrain_begin(), b.fulltrain_begin()
+    b.set_small_batch_tiles(0)                       # b: classic encoder path (what batches > 20480 leaves use)
+    ga, gb = _hip_grads(a, weights, x), _hip_grads(b, weights, x)
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    a.close(), b.close()
