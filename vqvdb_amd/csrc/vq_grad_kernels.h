@@ -402,6 +402,55 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
         }
     }
 }
+// Weight gradient of the 16 -> 16, k3 p1 layers at 8^3 with row reuse: one wave per (kd, kh, tile group, row chunk).  For an output row
+// (od, oh) the 8 dY blocks and the 8 X' blocks of the input row (od+kd-1, oh+kh-1) are staged once in LDS and serve the three kw taps
+// (22 block products from 16 block loads instead of 44: the tap-major kernel is bound by re-reading blocks from L2).
+// part layout as wgrad32_k: part[((grp*n_chunks + chunk)*27 + tap)*256 + co*16 + ci].
+__global__ __launch_bounds__(192) void wgrad16_rows_k(WgradArgs A, int n_chunks)
+{
+    __shared__ float sdy[8][16][33];
+    __shared__ float sx[8][16][33];
+    const int kdkh = blockIdx.x, kd = kdkh / 3, kh = kdkh % 3, grp = blockIdx.y, chunk = blockIdx.z;
+    const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6;   // three waves: one kw tap each, staging shared
+    const int t0 = grp * A.tiles_per_group, t1 = min(A.n_tiles, t0 + A.tiles_per_group);
+    const int r0 = chunk * 64 / n_chunks, r1 = (chunk + 1) * 64 / n_chunks;   // output rows (od*8 + oh) of this chunk
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int tile = t0; tile < t1; ++tile) {
+        for (int row = r0; row < r1; ++row) {
+            const int id = (row >> 3) + kd - 1, ih = (row & 7) + kh - 1;
+            if (id < 0 || id > 7 || ih < 0 || ih > 7) continue;   // wave-uniform
+            __syncthreads();
+            for (int i = threadIdx.x; i < 8 * 4 * 32; i += 192) {   // 8 positions x 4 quads x 32 leaves, float4 each
+                const int leaf = i & 31, quad = (i >> 5) & 3, w = i >> 7;
+                const f32x4 v = ((const f32x4*)A.dy)[(((size_t)tile * 512 + row * 8 + w) * 4 + quad) * 32 + leaf];
+                float* d = &sdy[w][4 * quad][leaf];
+                d[0] = v.x, d[33] = v.y, d[66] = v.z, d[99] = v.w;
+                const f32x4 xv = ((const f32x4*)A.x)[(((size_t)tile * 512 + (id * 8 + ih) * 8 + w) * 4 + quad) * 32 + leaf];
+                float o[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {   // X' = relu(GroupNorm(8,16)(X)) as the forward conv formed it
+                    const int ch = 4 * quad + k, gidx = ch >> 1;
+                    const float ia = A.rstd[((size_t)tile * 8 + gidx) * 32 + leaf] * A.gamma[ch];
+                    const float ib = __builtin_fmaf(-A.mean[((size_t)tile * 8 + gidx) * 32 + leaf], ia, A.beta[ch]);
+                    sx[w][ch][leaf] = fmaxf(__builtin_fmaf(o[k], ia, ib), 0.0f);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) {
+                const int iw = ow + kw - 1;
+                if (iw < 0 || iw > 7) continue;   // wave-uniform
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    acc = mfma16(sdy[ow][lane & 15][4 * m + (lane >> 4)], sx[iw][lane & 15][4 * m + (lane >> 4)], acc);
+            }
+        }
+    }
+    float* dst = A.part + (((size_t)grp * n_chunks + chunk) * 27 + kdkh * 3 + kw) * 256;
+    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = v[r];
+}
 // dW[(row0+co)*IC + ci][tap] = scale * sum_grp part[grp][tap][co][ci]
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ part, int n_groups, int KT, int COUT, int CIN, float* __restrict__ dW, int row0,
                                                       int IC, float scale)
