@@ -115,6 +115,13 @@ static void korder_p16(int* ord)
     for (int i = 0; i < 4; ++i)
         for (int q = 0; q < 4; ++q) ord[i * 4 + q] = 4 * q + i;
 }
+/* blocks of 16 channels ascending, "P16" inside each block (the decoder's 64 -> 64 convs on the 16x16x4 MFMA) */
+static void korder_p16_blocks(int cin, int* ord)
+{
+    int p[16];
+    korder_p16(p);
+    for (int c = 0; c < cin; ++c) ord[c] = (c & ~15) + p[c & 15];
+}
 
 /* ---- conv3d, activations [C][S^3][LT] ----
  * CB output channels are computed together only for instruction-level parallelism; every
@@ -615,8 +622,8 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
 static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0, int nl, float* out,
                         float* const* dbg, scratch_t* s, const tail_t* tail, int unfolded)
 {
-    int p8_64[64], p8_128[128];
-    korder_p8(64, p8_64); korder_p8(128, p8_128);
+    int p8_64[64], p8_128[128], p16b_64[64];
+    korder_p8(64, p8_64); korder_p8(128, p8_128); korder_p16_blocks(64, p16b_64);
     const float* E = W[W_CODEBOOK];
     float* q = s->a; /* [128][64][LT] */
     for (int c = 0; c < 128; ++c)
@@ -636,7 +643,7 @@ static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0
     float* x6 = s->d;
     float* y4tmp = NULL;
     if (dbg && dbg[DBG_D_Y4]) y4tmp = (float*)malloc(sizeof(float) * 64 * 64 * LT);
-    res_block(d2, x6, s->a, s->b, 64, 4, W, W_D_R64_GN1_W, p8_64, y4tmp);
+    res_block(d2, x6, s->a, s->b, 64, 4, W, W_D_R64_GN1_W, p16b_64, y4tmp);
     if (y4tmp) { dump(dbg[DBG_D_Y4], y4tmp, 64, 64, leaf0, nl); free(y4tmp); }
     if (dbg) dump(dbg[DBG_D_X6], x6, 64, 64, leaf0, nl);
     float* x7 = s->a;

@@ -921,6 +921,177 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_rows32_k(ConvArgs A, const in
 }
 
 // ------------------------------------------------------------------------------------------
+// D3/D5: Conv3d(64->64,k3,p1) @4^3 inside the decoder's ResidualBlock(64) (VQVAE_v2.py:190-210, :260), row-blocked on the
+// 16x16x4 MFMA.  A wave owns a 16-leaf HALF tile and one output row of 4 positions (16 accumulators of 16 couts x 16 leaves);
+// one step = (output row, valid (kd,kh)): the 4 input positions of the row sit in a rolling register buffer (GroupNorm+ReLU
+// applied on arrival), each feeds its 2-3 (ow,kw) pairs and is re-loaded for the next step right after its last use -> 6.25
+// row loads per output row instead of 15.6 position loads per output position (2.5x less re-fetch than one tap per step).
+// Weights: the 3 kw taps of the step (48 KB) stream through a double-buffered LDS window by global_load_lds, shared by the
+// 8 waves (4 tiles) of the workgroup, one barrier per step (640 MFMAs).  K order inside a tap: 16-channel blocks ascending,
+// "P16" inside a block (0,4,8,12,1,5,...) - restated by the oracle for these two layers.
+// wfrag[((tap*4 + cb)*4 + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
+// ------------------------------------------------------------------------------------------
+template <bool RESID, int GOUT, bool CSUM>
+__global__ __launch_bounds__(512, 1) void conv_rows16_c64_k(ConvArgs A, const int4* __restrict__ steps)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* lds = (f32x4*)smem_raw;
+    constexpr int WTAP = 16 * 64, WSTEP = 3 * WTAP;   // float4 per tap / per step (3 kw taps)
+    constexpr int PIECES = WSTEP / (8 * 64);           // 1 KiB pieces per wave per step
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int half = blockIdx.x * 8 + wave;
+    const bool active = (half >> 1) < A.n_tiles;
+    if (!active) half = 2 * A.n_tiles - 1;
+    const int tile = half >> 1;
+    const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
+    float ta[4][4], tb[4][4];   // GroupNorm(8,64)+ReLU of the input: channel 16cb + 4q4 + i, group (c >> 3)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 16 * cb + 4 * q4 + i, g = c >> 3;
+            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + jj];
+            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + jj];
+            ta[cb][i] = rstd * A.in_gamma[c];
+            tb[cb][i] = __builtin_fmaf(-mean, ta[cb][i], A.in_beta[c]);
+        }
+    GnAcc st[GOUT > 0 ? 4 : 1];
+#pragma unroll
+    for (int k = 0; k < (GOUT > 0 ? 4 : 1); ++k) st[k].init();
+    f32x4 cs[CSUM ? 4 : 1];
+#pragma unroll
+    for (int k = 0; k < (CSUM ? 4 : 1); ++k) cs[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 16 * 32 + q4 * 32 + jj;   // + (pos*16 + 4cb)*32
+    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 64 * 16 * 32 + q4 * 32 + jj;
+    const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * 64 * 16 * 32 + q4 * 32 + jj : nullptr;
+    const f32x4* wg4 = (const f32x4*)A.wfrag;
+    const f32x4* bias4 = (const f32x4*)A.bias_frag;   // plain [64]: quad 4mt + q4
+    const int NS = A.n_steps;
+    int g0, g1;
+    split_range<16>(g0, g1);
+    int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
+    int4 e = steps[si];
+    int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
+    f32x4 xr[4][4];
+#pragma unroll
+    for (int iw = 0; iw < 4; ++iw)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) xr[iw][cb] = in4[((size_t)(e.x + iw) * 16 + 4 * cb) * 32];
+#pragma unroll
+    for (int pc = 0; pc < PIECES; ++pc) {
+        const int piece = wave * PIECES + pc;
+        glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEP + piece * 64);
+    }
+    for (int row = g0; row < g1; ++row) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ow = 0; ow < 4; ++ow)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        bool last;
+        do {
+#pragma unroll
+            for (int iw = 0; iw < 4; ++iw)   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    f32x4 v = xr[iw][cb];
+                    v.x = fmaxf(__builtin_fmaf(v.x, ta[cb][0], tb[cb][0]), 0.0f);
+                    v.y = fmaxf(__builtin_fmaf(v.y, ta[cb][1], tb[cb][1]), 0.0f);
+                    v.z = fmaxf(__builtin_fmaf(v.z, ta[cb][2], tb[cb][2]), 0.0f);
+                    v.w = fmaxf(__builtin_fmaf(v.w, ta[cb][3], tb[cb][3]), 0.0f);
+                    xr[iw][cb] = v;
+                }
+            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
+            __syncthreads();   // every wave's pieces of W(step) landed; every wave done reading W(step-1)
+            {
+                f32x4* dst = lds + ((si + 1) & 1) * WSTEP;
+#pragma unroll
+                for (int pc = 0; pc < PIECES; ++pc) {
+                    const int piece = wave * PIECES + pc;
+                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
+                }
+            }
+            const f32x4* wl = lds + (si & 1) * WSTEP + lane;
+#pragma unroll
+            for (int iw = 0; iw < 4; ++iw) {
+#pragma unroll
+                for (int ow = 0; ow < 4; ++ow) {
+                    const int kw = iw - ow + 1;
+                    if (kw < 0 || kw > 2) continue;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const f32x4 a = wl[((kw * 4 + cb) * 4 + mt) * 64];
+                            acc[ow][mt] = mfma16(a.x, xr[iw][cb].x, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a.y, xr[iw][cb].y, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a.z, xr[iw][cb].z, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a.w, xr[iw][cb].w, acc[ow][mt]);
+                        }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) xr[iw][cb] = in4[((size_t)(en.x + iw) * 16 + 4 * cb) * 32];   // next step's row (index clamped)
+            }
+            last = (e.w & 2) != 0;
+            e = en;
+            en = en2;
+            ++si;
+        } while (!last);
+        // ---- epilogue: the 4 positions of the row, ascending ----
+#pragma unroll
+        for (int ow = 0; ow < 4; ++ow) {
+            const size_t o = ((size_t)(row * 4 + ow) * 16) * 32;
+            f32x4 sk[RESID ? 4 : 1];
+            if (RESID) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) sk[mt] = skip4[o + (size_t)4 * mt * 32];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 v = acc[ow][mt] + bias4[4 * mt + q4];
+                if (RESID) {
+                    const f32x4 u = v * 0.1f;
+                    v = sk[mt] + u;
+                }
+                if (active) out4[o + (size_t)4 * mt * 32] = v;
+                if (GOUT > 0) {
+                    st[mt].add(v.x);
+                    st[mt].add(v.y);
+                    st[mt].add(v.z);
+                    st[mt].add(v.w);
+                }
+                if (CSUM) cs[mt] = cs[mt] + v;
+            }
+        }
+    }
+    if (!active) return;
+    if (GOUT > 0) {   // GroupNorm(8,64): group = quads (2g, 2g+1) = this lane's quad 4mt+q4 and its q4^1 neighbour (16 lanes away)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            double S = st[mt].s, Q = st[mt].q;
+            const int lo = __double2loint(S), hi = __double2hiint(S), lo2 = __double2loint(Q), hi2 = __double2hiint(Q);
+            S = S + __hiloint2double(__shfl_xor(hi, 16, 64), __shfl_xor(lo, 16, 64));
+            Q = Q + __hiloint2double(__shfl_xor(hi2, 16, 64), __shfl_xor(lo2, 16, 64));
+            float m, r;
+            gn_finish(S, Q, 1.0 / 512.0, m, r);
+            if ((q4 & 1) == 0) {
+                A.out_mean[((size_t)tile * 8 + 2 * mt + (q4 >> 1)) * 32 + jj] = m;
+                A.out_rstd[((size_t)tile * 8 + 2 * mt + (q4 >> 1)) * 32 + jj] = r;
+            }
+        }
+    }
+    if (CSUM) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float v[4] = {cs[mt].x, cs[mt].y, cs[mt].z, cs[mt].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.out_csum[((size_t)tile * 64 + 16 * mt + 4 * q4 + r) * 32 + jj] = v[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Encoder tail: ChannelAttention(32) (VQVAE_v2.py:242) -> Conv3d(32->128,k1) (:243) -> nearest
 // codebook row (:358-367), with the projection FOLDED into the search:  ||z||^2 is the same for
 // every code and z.e_k = x'.(P^T e_k) + b.e_k, so

@@ -235,6 +235,18 @@ std::vector<float> frag16(const float* W, int KT)
             for (int i = 0; i < 4; ++i) f[((size_t)tap * 64 + lane) * 4 + i] = W[((size_t)(lane & 15) * 16 + 4 * (lane >> 4) + i) * KT + tap];
     return f;
 }
+// 16x16x4 A-fragments for the 64 -> 64 decoder convs (conv_rows16_c64_k): [tap][cb][mt][lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
+std::vector<float> frag16x64(const float* W, int KT)
+{
+    std::vector<float> f((size_t)KT * 4 * 4 * 64 * 4);
+    for (int tap = 0; tap < KT; ++tap)
+        for (int cb = 0; cb < 4; ++cb)
+            for (int mt = 0; mt < 4; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 4; ++i)
+                        f[((((size_t)tap * 4 + cb) * 4 + mt) * 64 + lane) * 4 + i] = W[((size_t)(16 * mt + (lane & 15)) * 64 + 16 * cb + 4 * (lane >> 4) + i) * KT + tap];
+    return f;
+}
 // first conv: [(kd*3+kh)][lane] = W[cout = lane&15][0][kd][kh][kw = lane>>4] (0 for the pad slot)
 std::vector<float> frag_first(const float* W)
 {
@@ -556,6 +568,7 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ds.w", dsw) UP("ds.b", dsb) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
     UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
+    UP("r64c1.w16", frag16x64(r64c1w->data, 27)) UP("r64c1.braw", r64c1b) UP("r64c2.w16", frag16x64(r64c2w->data, 27)) UP("r64c2.braw", r64c2b)
     UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
     UP("cb", cb)
     c->h_proj_w.assign(epw->data, epw->data + 128 * 32);
@@ -665,9 +678,12 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 constexpr auto k_enc_down = conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 8, 0, 0, false, 8, false>;
 constexpr auto k_enc_r32c1 = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, false, 8, false>;
 constexpr auto k_enc_r32c2 = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, true, 0, true>;
-constexpr auto k_dec_r64c1 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, false, 8, false, 0>;
-constexpr auto k_dec_r64c2 = conv_mfma32_k<64, 64, 64, 64, 8, true, 1, 1, 8, true, 0, true, 0>;
 constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
+constexpr auto k_dec_r64c1_r = conv_rows16_c64_k<false, 8, false>;   // row-blocked 16x16x4 variants of the two res64 convs
+constexpr auto k_dec_r64c2_r = conv_rows16_c64_k<true, 0, true>;
+constexpr auto k_dec_r64c1_rs = conv_rows16_c64_k<false, 0, false>;  // ... without fused statistics (position-split launches)
+constexpr auto k_dec_r64c2_rs = conv_rows16_c64_k<true, 0, false>;
+constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 KB weight window
 constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
 constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
@@ -686,6 +702,10 @@ constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + pr
 int init_kernel_attrs(vqhip_codec* c)
 {
     int rc;
+    if ((rc = set_lds(c, k_dec_r64c1_r, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c2_r, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c1_rs, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c2_rs, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_enc_down_s, LDS_ENC_DOWN))) return rc;
     if ((rc = set_lds(c, k_enc_r32c1_s, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, k_enc_r32c2_s, LDS_ENC_R32))) return rc;
@@ -878,12 +898,14 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         ConvArgs A{};
         A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27, A.grp_start = od("steps.k3s1_4");
-        L.run("dec_res64_conv1_s", [&] { hipLaunchKernelGGL(k_dec_r64c1_s, dim3(g2, split_factor(g2, 4, 16, 1024)), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        A.wfrag = w["r64c1.w16"], A.bias_frag = w["r64c1.braw"];
+        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
+        const int gh = (2 * nt + 7) / 8, psr = split_factor(gh, 4, 16, 512);   // 8 half tiles per workgroup, 16 output rows to split
+        L.run("dec_res64_conv1_s", [&] { hipLaunchKernelGGL(k_dec_r64c1_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]); });
         L.run("dec_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_y4"], a["st_a.mean"], a["st_a.rstd"]); });
-        A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w"], A.bias_frag = w["r64c2.b"], A.skip = a["d_d2"];
+        A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w16"], A.bias_frag = w["r64c2.braw"], A.skip = a["d_d2"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
-        L.run("dec_res64_conv2_s", [&] { hipLaunchKernelGGL(k_dec_r64c2_s, dim3(g2, split_factor(g2, 4, 16, 1024)), dim3(128), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        L.run("dec_res64_conv2_s", [&] { hipLaunchKernelGGL(k_dec_r64c2_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]); });
         L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"]); });
     }
     {
@@ -906,7 +928,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
-    if (nt <= 2 * c->split_tiles) return decode_chunk_split(c, L, d_idx, n, d_out, s);  // the decoder's crossover is about twice the encoder's
+    if (nt <= 3 * c->split_tiles / 2) return decode_chunk_split(c, L, d_idx, n, d_out, s);  // the decoder's crossover is about 1.5x the encoder's
     L.run("dec_stem", [&] {
         hipLaunchKernelGGL(stem_lut_k, dim3(g4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
                            (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
@@ -922,16 +944,16 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
-        L.run("dec_res64_conv1", [&] { hipLaunchKernelGGL(k_dec_r64c1, dim3(g8), dim3(512), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        A.wfrag = w["r64c1.w16"], A.bias_frag = w["r64c1.braw"], A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
+        L.run("dec_res64_conv1", [&] { hipLaunchKernelGGL(k_dec_r64c1_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         ConvArgs A{};
         A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w"], A.bias_frag = w["r64c2.b"], A.skip = a["d_d2"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
         A.out_csum = a["csum"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.k3s1_4"], A.n_taps = 27;
-        L.run("dec_res64_conv2", [&] { hipLaunchKernelGGL(k_dec_r64c2, dim3(g8), dim3(512), LDS_DEC_R64, s, A, (const int4*)w["steps.k3s1_4"]); });
+        A.wfrag = w["r64c2.w16"], A.bias_frag = w["r64c2.braw"], A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
+        L.run("dec_res64_conv2", [&] { hipLaunchKernelGGL(k_dec_r64c2_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         ConvArgs A{};
