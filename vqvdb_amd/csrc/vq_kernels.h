@@ -1020,15 +1020,19 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_c64_k(ConvArgs A, const in
                     const int kw = iw - ow + 1;
                     if (kw < 0 || kw > 2) continue;
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
+                    for (int cb = 0; cb < 4; ++cb) {
+                        f32x4 a[4];   // the 4 cout tiles of this (tap, channel block): 4 LDS reads ahead of their 16 MFMAs, no further
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) a[mt] = wl[((kw * 4 + cb) * 4 + mt) * 64];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            const f32x4 a = wl[((kw * 4 + cb) * 4 + mt) * 64];
-                            acc[ow][mt] = mfma16(a.x, xr[iw][cb].x, acc[ow][mt]);
-                            acc[ow][mt] = mfma16(a.y, xr[iw][cb].y, acc[ow][mt]);
-                            acc[ow][mt] = mfma16(a.z, xr[iw][cb].z, acc[ow][mt]);
-                            acc[ow][mt] = mfma16(a.w, xr[iw][cb].w, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a[mt].x, xr[iw][cb].x, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a[mt].y, xr[iw][cb].y, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a[mt].z, xr[iw][cb].z, acc[ow][mt]);
+                            acc[ow][mt] = mfma16(a[mt].w, xr[iw][cb].w, acc[ow][mt]);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) xr[iw][cb] = in4[((size_t)(en.x + iw) * 16 + 4 * cb) * 32];   // next step's row (index clamped)
