@@ -543,12 +543,13 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
     if (y4tmp) { dump(dbg[DBG_E_Y4], y4tmp, 16, 512, leaf0, nl); free(y4tmp); }
     if (dbg) dump(dbg[DBG_E_A6], a6, 16, 512, leaf0, nl);
     float* x7 = s->c;
-    conv3d(a6, x7, W[W_E_DOWN_W], W[W_E_DOWN_B], 16, 32, 8, 4, 4, 2, 1, p8_16);
+    conv3d(a6, x7, W[W_E_DOWN_W], W[W_E_DOWN_B], 16, 32, 8, 4, 4, 2, 1, p16);
     if (dbg) dump(dbg[DBG_E_X7], x7, 32, 64, leaf0, nl);
     float* x11 = s->d;
     float* y9tmp = NULL;
     if (dbg && dbg[DBG_E_Y9]) y9tmp = (float*)malloc(sizeof(float) * 32 * 64 * LT);
-    res_block(x7, x11, s->a, s->b, 32, 4, W, W_E_R32_GN1_W, p8_32, y9tmp);
+    int p16b_32[32]; korder_p16_blocks(32, p16b_32);
+    res_block(x7, x11, s->a, s->b, 32, 4, W, W_E_R32_GN1_W, p16b_32, y9tmp);
     if (y9tmp) { dump(dbg[DBG_E_Y9], y9tmp, 32, 64, leaf0, nl); free(y9tmp); }
     if (dbg) dump(dbg[DBG_E_X11], x11, 32, 64, leaf0, nl);
     float* x12 = s->a;

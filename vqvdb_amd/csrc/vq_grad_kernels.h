@@ -38,13 +38,18 @@ __global__ __launch_bounds__(256) void refrag16_k(const float* __restrict__ W, f
         dst[t] = scale * (transpose ? W[(ci * 16 + co) * KT + (KT - 1 - tap)] : W[(co * 16 + ci) * KT + tap]);
     }
 }
-// 16x16x4 fragments of the 64 -> 64 decoder convs (conv_rows16_c64_k): [tap][cb][mt][lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
-__global__ __launch_bounds__(256) void refrag16x64_k(const float* __restrict__ W, float* __restrict__ dst, int KT)
+// 16x16x4 fragments of conv_rows16_k: [tap][cb][mt][lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
+__global__ __launch_bounds__(256) void refrag16g_k(const float* __restrict__ W, float* __restrict__ dst, int COUT, int CIN, int KT)
 {
-    const int total = KT * 4 * 4 * 64 * 4;
+    const int CBN = CIN / 16, MTN = COUT / 16;
+    const int total = KT * CBN * MTN * 256;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int i = t & 3, lane = (t >> 2) & 63, mt = (t >> 8) & 3, cb = (t >> 10) & 3, tap = t >> 12;
-        dst[t] = W[((size_t)(16 * mt + (lane & 15)) * 64 + 16 * cb + 4 * (lane >> 4) + i) * KT + tap];
+        const int i = t & 3, lane = (t >> 2) & 63;
+        int r = t >> 8;
+        const int mt = r % MTN;
+        r /= MTN;
+        const int cb = r % CBN, tap = r / CBN;
+        dst[t] = W[((size_t)(16 * mt + (lane & 15)) * CIN + 16 * cb + 4 * (lane >> 4) + i) * KT + tap];
     }
 }
 __global__ __launch_bounds__(64) void refrag_first_k(const float* __restrict__ W, float* __restrict__ dst)

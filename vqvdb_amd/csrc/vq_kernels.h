@@ -921,23 +921,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_rows32_k(ConvArgs A, const in
 }
 
 // ------------------------------------------------------------------------------------------
-// D3/D5: Conv3d(64->64,k3,p1) @4^3 inside the decoder's ResidualBlock(64) (VQVAE_v2.py:190-210, :260), row-blocked on the
-// 16x16x4 MFMA.  A wave owns a 16-leaf HALF tile and one output row of 4 positions (16 accumulators of 16 couts x 16 leaves);
-// one step = (output row, valid (kd,kh)): the 4 input positions of the row sit in a rolling register buffer (GroupNorm+ReLU
-// applied on arrival), each feeds its 2-3 (ow,kw) pairs and is re-loaded for the next step right after its last use -> 6.25
-// row loads per output row instead of 15.6 position loads per output position (2.5x less re-fetch than one tap per step).
-// Weights: the 3 kw taps of the step (48 KB) stream through a double-buffered LDS window by global_load_lds, shared by the
-// 8 waves (4 tiles) of the workgroup, one barrier per step (640 MFMAs).  K order inside a tap: 16-channel blocks ascending,
-// "P16" inside a block (0,4,8,12,1,5,...) - restated by the oracle for these two layers.
-// wfrag[((tap*4 + cb)*4 + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
+// Row-blocked leaf-tile conv on the 16x16x4 MFMA for every layer with a 4^3 output: the decoder's ResidualBlock(64) convs
+// (VQVAE_v2.py:190-210, :260), the encoder's ResidualBlock(32) convs (:240) and the down conv 16->32 k4 s2 (:239).
+// A wave owns a 16-leaf HALF tile and one output row of SO = 4 positions (SO x COUT/16 accumulators of 16 couts x 16 leaves);
+// one step = (output row, valid (kd,kh)): the SI input positions of the row sit in a rolling register buffer (GroupNorm+ReLU
+// applied on arrival), each feeds its (ow,kw) pairs and is re-loaded for the next step right after its last use (k3: 6.25 row
+// loads per output row instead of 15.6 position loads per output position).  Weights: the KS kw-taps of the step stream
+// through a double-buffered LDS window by global_load_lds, shared by the 8 waves (4 tiles) of the workgroup, one barrier per
+// step (64->64: 640 MFMAs).  K order inside a tap: 16-channel blocks ascending, "P16" inside a block (0,4,8,12,1,5,...),
+// restated by the oracle for these layers.  Less HBM re-fetch also means a higher sustained clock: the 64->64 layers went from
+// 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
+// wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <bool RESID, int GOUT, bool CSUM>
-__global__ __launch_bounds__(512, 1) void conv_rows16_c64_k(ConvArgs A, const int4* __restrict__ steps)
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false>
+__global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
-    constexpr int WTAP = 16 * 64, WSTEP = 3 * WTAP;   // float4 per tap / per step (3 kw taps)
-    constexpr int PIECES = WSTEP / (8 * 64);           // 1 KiB pieces per wave per step
+    constexpr int CBN = CIN / 16, MTN = COUT / 16, NPI = SI * SI * SI, NPO = SO * SO * SO;
+    constexpr int WTAP = CBN * MTN * 64, WSTEP = KS * WTAP;   // float4 per tap / per step (KS kw taps)
+    static_assert(INMODE == 0 || INMODE == 1, "raw or GroupNorm(8)+ReLU input");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int half = blockIdx.x * 8 + wave;
@@ -945,114 +948,116 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_c64_k(ConvArgs A, const in
     if (!active) half = 2 * A.n_tiles - 1;
     const int tile = half >> 1;
     const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
-    float ta[4][4], tb[4][4];   // GroupNorm(8,64)+ReLU of the input: channel 16cb + 4q4 + i, group (c >> 3)
+    float ta[INMODE == 1 ? CBN : 1][4], tb[INMODE == 1 ? CBN : 1][4];   // input channel 16cb + 4q4 + i, GroupNorm(8, CIN)
+    if (INMODE == 1) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < CBN; ++cb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = 16 * cb + 4 * q4 + i, g = c >> 3;
-            const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + jj];
-            const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + jj];
-            ta[cb][i] = rstd * A.in_gamma[c];
-            tb[cb][i] = __builtin_fmaf(-mean, ta[cb][i], A.in_beta[c]);
-        }
-    GnAcc st[GOUT > 0 ? 4 : 1];
+            for (int i = 0; i < 4; ++i) {
+                const int c = 16 * cb + 4 * q4 + i, g = c / (CIN / 8);
+                const float mean = A.in_mean[((size_t)tile * 8 + g) * 32 + jj];
+                const float rstd = A.in_rstd[((size_t)tile * 8 + g) * 32 + jj];
+                ta[cb][i] = rstd * A.in_gamma[c];
+                tb[cb][i] = __builtin_fmaf(-mean, ta[cb][i], A.in_beta[c]);
+            }
+    }
+    GnAcc st[GOUT > 0 ? MTN : 1];
 #pragma unroll
-    for (int k = 0; k < (GOUT > 0 ? 4 : 1); ++k) st[k].init();
-    f32x4 cs[CSUM ? 4 : 1];
+    for (int k = 0; k < (GOUT > 0 ? MTN : 1); ++k) st[k].init();
+    f32x4 cs[CSUM ? MTN : 1];
 #pragma unroll
-    for (int k = 0; k < (CSUM ? 4 : 1); ++k) cs[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 64 * 16 * 32 + q4 * 32 + jj;   // + (pos*16 + 4cb)*32
-    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 64 * 16 * 32 + q4 * 32 + jj;
-    const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * 64 * 16 * 32 + q4 * 32 + jj : nullptr;
+    for (int k = 0; k < (CSUM ? MTN : 1); ++k) cs[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q4 * 32 + jj;   // + (pos*(CIN/4) + 4cb)*32
+    f32x4* out4 = (f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj;
+    const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj : nullptr;
     const f32x4* wg4 = (const f32x4*)A.wfrag;
-    const f32x4* bias4 = (const f32x4*)A.bias_frag;   // plain [64]: quad 4mt + q4
+    const f32x4* bias4 = (const f32x4*)A.bias_frag;   // plain [COUT]: quad 4mt + q4
     const int NS = A.n_steps;
     int g0, g1;
-    split_range<16>(g0, g1);
+    split_range<SO * SO>(g0, g1);
     int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
-    f32x4 xr[4][4];
+    f32x4 xr[SI][CBN];
 #pragma unroll
-    for (int iw = 0; iw < 4; ++iw)
+    for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) xr[iw][cb] = in4[((size_t)(e.x + iw) * 16 + 4 * cb) * 32];
-#pragma unroll
-    for (int pc = 0; pc < PIECES; ++pc) {
-        const int piece = wave * PIECES + pc;
-        glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEP + piece * 64);
+        for (int cb = 0; cb < CBN; ++cb) xr[iw][cb] = in4[((size_t)(e.x + iw) * (CIN / 4) + 4 * cb) * 32];
+    if (RESIDENT) {   // all taps of the layer stay in LDS (A.n_taps x WTAP float4): no per-step barrier
+        for (int i = threadIdx.x; i < A.n_taps * WTAP; i += 512) lds[i] = wg4[i];
+        __syncthreads();
+    } else {
+        for (int piece = wave; piece < WSTEP / 64; piece += 8) glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEP + piece * 64);
     }
     for (int row = g0; row < g1; ++row) {
-        f32x4 acc[4][4];
+        f32x4 acc[SO][MTN];
 #pragma unroll
-        for (int ow = 0; ow < 4; ++ow)
+        for (int ow = 0; ow < SO; ++ow)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int mt = 0; mt < MTN; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         bool last;
         do {
+            if (INMODE == 1) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
 #pragma unroll
-            for (int iw = 0; iw < 4; ++iw)   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
+                for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    f32x4 v = xr[iw][cb];
-                    v.x = fmaxf(__builtin_fmaf(v.x, ta[cb][0], tb[cb][0]), 0.0f);
-                    v.y = fmaxf(__builtin_fmaf(v.y, ta[cb][1], tb[cb][1]), 0.0f);
-                    v.z = fmaxf(__builtin_fmaf(v.z, ta[cb][2], tb[cb][2]), 0.0f);
-                    v.w = fmaxf(__builtin_fmaf(v.w, ta[cb][3], tb[cb][3]), 0.0f);
-                    xr[iw][cb] = v;
-                }
-            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
-            __syncthreads();   // every wave's pieces of W(step) landed; every wave done reading W(step-1)
-            {
-                f32x4* dst = lds + ((si + 1) & 1) * WSTEP;
-#pragma unroll
-                for (int pc = 0; pc < PIECES; ++pc) {
-                    const int piece = wave * PIECES + pc;
-                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
-                }
+                    for (int cb = 0; cb < CBN; ++cb) {
+                        f32x4 v = xr[iw][cb];
+                        v.x = fmaxf(__builtin_fmaf(v.x, ta[cb][0], tb[cb][0]), 0.0f);
+                        v.y = fmaxf(__builtin_fmaf(v.y, ta[cb][1], tb[cb][1]), 0.0f);
+                        v.z = fmaxf(__builtin_fmaf(v.z, ta[cb][2], tb[cb][2]), 0.0f);
+                        v.w = fmaxf(__builtin_fmaf(v.w, ta[cb][3], tb[cb][3]), 0.0f);
+                        xr[iw][cb] = v;
+                    }
             }
-            const f32x4* wl = lds + (si & 1) * WSTEP + lane;
+            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
+            if (!RESIDENT) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight pieces and input row have landed
+                __syncthreads();                      // every wave's pieces of W(step) landed; every wave done reading W(step-1)
+                f32x4* dst = lds + ((si + 1) & 1) * WSTEP;
+                for (int piece = wave; piece < WSTEP / 64; piece += 8) glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
+            }
+            const f32x4* wl = (RESIDENT ? lds + (size_t)e.y * WTAP : lds + (si & 1) * WSTEP) + lane;
 #pragma unroll
-            for (int iw = 0; iw < 4; ++iw) {
+            for (int iw = 0; iw < SI; ++iw) {
 #pragma unroll
-                for (int ow = 0; ow < 4; ++ow) {
-                    const int kw = iw - ow + 1;
-                    if (kw < 0 || kw > 2) continue;
+                for (int ow = 0; ow < SO; ++ow) {
+                    const int kw = iw - ow * STRIDE + PAD;
+                    if (kw < 0 || kw >= KS) continue;
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        f32x4 a[4];   // the 4 cout tiles of this (tap, channel block): 4 LDS reads ahead of their 16 MFMAs, no further
+                    for (int cb = 0; cb < CBN; ++cb) {
+                        f32x4 a[MTN];   // the cout tiles of this (tap, channel block): MTN LDS reads ahead of their MFMAs, no further
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) a[mt] = wl[((kw * 4 + cb) * 4 + mt) * 64];
+                        for (int mt = 0; mt < MTN; ++mt) a[mt] = wl[((kw * CBN + cb) * MTN + mt) * 64];
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
+                        for (int mt = 0; mt < MTN; ++mt) {
                             acc[ow][mt] = mfma16(a[mt].x, xr[iw][cb].x, acc[ow][mt]);
                             acc[ow][mt] = mfma16(a[mt].y, xr[iw][cb].y, acc[ow][mt]);
                             acc[ow][mt] = mfma16(a[mt].z, xr[iw][cb].z, acc[ow][mt]);
                             acc[ow][mt] = mfma16(a[mt].w, xr[iw][cb].w, acc[ow][mt]);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (MTN >= 4) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) xr[iw][cb] = in4[((size_t)(en.x + iw) * 16 + 4 * cb) * 32];   // next step's row (index clamped)
+                for (int cb = 0; cb < CBN; ++cb) xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
             }
             last = (e.w & 2) != 0;
             e = en;
             en = en2;
             ++si;
         } while (!last);
-        // ---- epilogue: the 4 positions of the row, ascending ----
+        // ---- epilogue: the SO positions of the row, ascending ----
 #pragma unroll
-        for (int ow = 0; ow < 4; ++ow) {
-            const size_t o = ((size_t)(row * 4 + ow) * 16) * 32;
-            f32x4 sk[RESID ? 4 : 1];
+        for (int ow = 0; ow < SO; ++ow) {
+            const size_t o = ((size_t)(row * SO + ow) * (COUT / 4)) * 32;
+            f32x4 sk[RESID ? MTN : 1];
             if (RESID) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) sk[mt] = skip4[o + (size_t)4 * mt * 32];
+                for (int mt = 0; mt < MTN; ++mt) sk[mt] = skip4[o + (size_t)4 * mt * 32];
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MTN; ++mt) {
                 f32x4 v = acc[ow][mt] + bias4[4 * mt + q4];
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
@@ -1070,27 +1075,33 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_c64_k(ConvArgs A, const in
         }
     }
     if (!active) return;
-    if (GOUT > 0) {   // GroupNorm(8,64): group = quads (2g, 2g+1) = this lane's quad 4mt+q4 and its q4^1 neighbour (16 lanes away)
+    if (GOUT > 0) {
+        constexpr int CPGO = COUT / 8;
+        static_assert(GOUT == 0 || (GOUT == 8 && (CPGO == 4 || CPGO == 8)), "GroupNorm(8, COUT) with COUT = 32 or 64");
+        const double inv_n = 1.0 / (double)(CPGO * NPO);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MTN; ++mt) {
             double S = st[mt].s, Q = st[mt].q;
-            const int lo = __double2loint(S), hi = __double2hiint(S), lo2 = __double2loint(Q), hi2 = __double2hiint(Q);
-            S = S + __hiloint2double(__shfl_xor(hi, 16, 64), __shfl_xor(lo, 16, 64));
-            Q = Q + __hiloint2double(__shfl_xor(hi2, 16, 64), __shfl_xor(lo2, 16, 64));
+            if (CPGO == 8) {   // group = quads (2g, 2g+1) = this lane's quad 4mt+q4 and its q4^1 neighbour (16 lanes away): low + high
+                const int lo = __double2loint(S), hi = __double2hiint(S), lo2 = __double2loint(Q), hi2 = __double2hiint(Q);
+                S = S + __hiloint2double(__shfl_xor(hi, 16, 64), __shfl_xor(lo, 16, 64));
+                Q = Q + __hiloint2double(__shfl_xor(hi2, 16, 64), __shfl_xor(lo2, 16, 64));
+            }
             float m, r;
-            gn_finish(S, Q, 1.0 / 512.0, m, r);
-            if ((q4 & 1) == 0) {
-                A.out_mean[((size_t)tile * 8 + 2 * mt + (q4 >> 1)) * 32 + jj] = m;
-                A.out_rstd[((size_t)tile * 8 + 2 * mt + (q4 >> 1)) * 32 + jj] = r;
+            gn_finish(S, Q, inv_n, m, r);
+            const int grp = CPGO == 8 ? 2 * mt + (q4 >> 1) : 4 * mt + q4;
+            if (CPGO == 4 || (q4 & 1) == 0) {
+                A.out_mean[((size_t)tile * 8 + grp) * 32 + jj] = m;
+                A.out_rstd[((size_t)tile * 8 + grp) * 32 + jj] = r;
             }
         }
     }
     if (CSUM) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MTN; ++mt) {
             const float v[4] = {cs[mt].x, cs[mt].y, cs[mt].z, cs[mt].w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A.out_csum[((size_t)tile * 64 + 16 * mt + 4 * q4 + r) * 32 + jj] = v[r];
+            for (int r = 0; r < 4; ++r) A.out_csum[((size_t)tile * COUT + 16 * mt + 4 * q4 + r) * 32 + jj] = v[r];
         }
     }
 }

@@ -235,16 +235,18 @@ std::vector<float> frag16(const float* W, int KT)
             for (int i = 0; i < 4; ++i) f[((size_t)tap * 64 + lane) * 4 + i] = W[((size_t)(lane & 15) * 16 + 4 * (lane >> 4) + i) * KT + tap];
     return f;
 }
-// 16x16x4 A-fragments for the 64 -> 64 decoder convs (conv_rows16_c64_k): [tap][cb][mt][lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
-std::vector<float> frag16x64(const float* W, int KT)
+// 16x16x4 A-fragments of conv_rows16_k: [tap][cb][mt][lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
+std::vector<float> frag16g(const float* W, int COUT, int CIN, int KT)
 {
-    std::vector<float> f((size_t)KT * 4 * 4 * 64 * 4);
+    const int CBN = CIN / 16, MTN = COUT / 16;
+    std::vector<float> f((size_t)KT * CBN * MTN * 64 * 4);
     for (int tap = 0; tap < KT; ++tap)
-        for (int cb = 0; cb < 4; ++cb)
-            for (int mt = 0; mt < 4; ++mt)
+        for (int cb = 0; cb < CBN; ++cb)
+            for (int mt = 0; mt < MTN; ++mt)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int i = 0; i < 4; ++i)
-                        f[((((size_t)tap * 4 + cb) * 4 + mt) * 64 + lane) * 4 + i] = W[((size_t)(16 * mt + (lane & 15)) * 64 + 16 * cb + 4 * (lane >> 4) + i) * KT + tap];
+                        f[((((size_t)tap * CBN + cb) * MTN + mt) * 64 + lane) * 4 + i] =
+                            W[((size_t)(16 * mt + (lane & 15)) * CIN + 16 * cb + 4 * (lane >> 4) + i) * KT + tap];
     return f;
 }
 // first conv: [(kd*3+kh)][lane] = W[cout = lane&15][0][kd][kh][kw = lane>>4] (0 for the pad slot)
@@ -568,7 +570,9 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ds.w", dsw) UP("ds.b", dsb) UP("dg0.w", dg0w) UP("dg0.b", dg0b)
     UP("r64g1.w", r64g1w) UP("r64g1.b", r64g1b) UP("r64c1.w", frag32(r64c1w->data, 64, 64, 27)) UP("r64c1.b", dfrag32(r64c1b->data, 64))
     UP("r64g2.w", r64g2w) UP("r64g2.b", r64g2b) UP("r64c2.w", frag32(r64c2w->data, 64, 64, 27)) UP("r64c2.b", dfrag32(r64c2b->data, 64))
-    UP("r64c1.w16", frag16x64(r64c1w->data, 27)) UP("r64c1.braw", r64c1b) UP("r64c2.w16", frag16x64(r64c2w->data, 27)) UP("r64c2.braw", r64c2b)
+    UP("r64c1.w16", frag16g(r64c1w->data, 64, 64, 27)) UP("r64c1.braw", r64c1b) UP("r64c2.w16", frag16g(r64c2w->data, 64, 64, 27)) UP("r64c2.braw", r64c2b)
+    UP("r32c1.w16", frag16g(r32c1w->data, 32, 32, 27)) UP("r32c1.braw", r32c1b) UP("r32c2.w16", frag16g(r32c2w->data, 32, 32, 27)) UP("r32c2.braw", r32c2b)
+    UP("ed.w16", frag16g(edw->data, 32, 16, 64)) UP("ed.braw", edb)
     UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
     UP("cb", cb)
     c->h_proj_w.assign(epw->data, epw->data + 128 * 32);
@@ -675,14 +679,20 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 // kernel instantiations -------------------------------------------------------------------
 //                                          CIN COUT NPI NPO NW STREAM KWG INMODE GIN RESID GOUT CSUM  OUTMODE
 //                                        CIN COUT SI SO KS ST PD NW INMODE GIN RESID GOUT CSUM
-constexpr auto k_enc_down = conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 8, 0, 0, false, 8, false>;
-constexpr auto k_enc_r32c1 = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, false, 8, false>;
-constexpr auto k_enc_r32c2 = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 8, 1, 8, true, 0, true>;
 constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
-constexpr auto k_dec_r64c1_r = conv_rows16_c64_k<false, 8, false>;   // row-blocked 16x16x4 variants of the two res64 convs
-constexpr auto k_dec_r64c2_r = conv_rows16_c64_k<true, 0, true>;
-constexpr auto k_dec_r64c1_rs = conv_rows16_c64_k<false, 0, false>;  // ... without fused statistics (position-split launches)
-constexpr auto k_dec_r64c2_rs = conv_rows16_c64_k<true, 0, false>;
+//                                           CIN COUT SI SO KS ST PD INMODE RESID GOUT CSUM
+constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false>;   // row-blocked 16x16x4 convs (4^3 outputs)
+constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true>;
+constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (position-split launches)
+constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
+constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true>;    // weights LDS-resident
+constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true>;
+constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true>;
+constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 0, false, true>;
+constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true>;
+constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, false, true>;
+constexpr size_t LDS_ENC_DOWN_R = (size_t)64 * (1 * 2 * 64) * 16;   // 128 KB, resident
+constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, resident
 constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 KB weight window
 constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
@@ -693,27 +703,24 @@ constexpr auto k_dec_r64c1_s = conv_mfma32_k<64, 64, 64, 64, 2, true, 1, 1, 8, f
 constexpr auto k_dec_r64c2_s = conv_mfma32_k<64, 64, 64, 64, 2, true, 1, 1, 8, true, 0, false, 0>;
 constexpr auto k_dec_tail_s = conv_mfma32_k<64, 128, 64, 4, 2, true, 1, 2, 0, false, 0, false, 2>;
 // position-split (small-batch) variants: 2 tiles per workgroup, no fused statistics
-constexpr auto k_enc_down_s = conv_rows32_k<16, 32, 8, 4, 4, 2, 1, 2, 0, 0, false, 0, false>;
-constexpr auto k_enc_r32c1_s = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 2, 1, 8, false, 0, false>;
-constexpr auto k_enc_r32c2_s = conv_rows32_k<32, 32, 4, 4, 3, 1, 1, 2, 1, 8, true, 0, false>;
 
 constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + projection A-fragments (144 KB)
 
 int init_kernel_attrs(vqhip_codec* c)
 {
     int rc;
+    if ((rc = set_lds(c, k_enc_down_r, LDS_ENC_DOWN_R))) return rc;
+    if ((rc = set_lds(c, k_enc_down_rs, LDS_ENC_DOWN_R))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c1_r, LDS_ENC_R32R))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c1_rs, LDS_ENC_R32R))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c2_r, LDS_ENC_R32R))) return rc;
+    if ((rc = set_lds(c, k_enc_r32c2_rs, LDS_ENC_R32R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c1_r, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_r, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c1_rs, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rs, LDS_DEC_R64R))) return rc;
-    if ((rc = set_lds(c, k_enc_down_s, LDS_ENC_DOWN))) return rc;
-    if ((rc = set_lds(c, k_enc_r32c1_s, LDS_ENC_R32))) return rc;
-    if ((rc = set_lds(c, k_enc_r32c2_s, LDS_ENC_R32))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
-    if ((rc = set_lds(c, k_enc_down, LDS_ENC_DOWN))) return rc;
-    if ((rc = set_lds(c, k_enc_r32c1, LDS_ENC_R32))) return rc;
-    if ((rc = set_lds(c, k_enc_r32c2, LDS_ENC_R32))) return rc;
     return VQHIP_OK;
 }
 
@@ -751,7 +758,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     auto& a = c->act;
     auto& w = c->dw;
     auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
-    const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
+    const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2, gh = (2 * nt + 7) / 8;   // gh: workgroups of 8 half tiles (conv_rows16_k)
     {
         ConvArgs A{};
         A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
@@ -776,21 +783,21 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     }
     {
         ConvArgs A{};
-        A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"], A.n_tiles = nt;
+        A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.grp_start = od("steps.rows_k4s2_8");
-        L.run("enc_down_s", [&] { hipLaunchKernelGGL(k_enc_down_s, dim3(g2, split_factor(g2, 4, 16, 512)), dim3(128), LDS_ENC_DOWN, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
+        L.run("enc_down_s", [&] { hipLaunchKernelGGL(k_enc_down_rs, dim3(gh, split_factor(gh, 4, 16, 512)), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
         L.run("enc_stats_x7", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_x7"], a["st_b.mean"], a["st_b.rstd"]); });
     }
     {
         ConvArgs A{};
-        A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
+        A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w16"], A.bias_frag = w["r32c1.braw"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
-        L.run("enc_res32_conv1_s", [&] { hipLaunchKernelGGL(k_enc_r32c1_s, dim3(g2, split_factor(g2, 4, 16, 512)), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv1_s", [&] { hipLaunchKernelGGL(k_enc_r32c1_rs, dim3(gh, split_factor(gh, 4, 16, 512)), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
         L.run("enc_stats_y9", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_y9"], a["st_a.mean"], a["st_a.rstd"]); });
-        A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
+        A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w16"], A.bias_frag = w["r32c2.braw"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
-        L.run("enc_res32_conv2_s", [&] { hipLaunchKernelGGL(k_enc_r32c2_s, dim3(g2, split_factor(g2, 4, 16, 512)), dim3(128), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv2_s", [&] { hipLaunchKernelGGL(k_enc_r32c2_rs, dim3(gh, split_factor(gh, 4, 16, 512)), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
         L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"]); });
     }
     if (d_latent) {
@@ -843,26 +850,26 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     }
     {
         ConvArgs A{};
-        A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w"], A.bias_frag = w["ed.b"];
+        A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"];
         A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64;
-        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down, dim3(g8), dim3(512), LDS_ENC_DOWN, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
+        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
     }
     {
         ConvArgs A{};
-        A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w"], A.bias_frag = w["r32c1.b"];
+        A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w16"], A.bias_frag = w["r32c1.braw"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
-        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         ConvArgs A{};
-        A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w"], A.bias_frag = w["r32c2.b"], A.skip = a["e_x7"];
+        A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w16"], A.bias_frag = w["r32c2.braw"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
         A.out_csum = a["csum"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
-        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2, dim3(g8), dim3(512), LDS_ENC_R32, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     if (d_latent) {
         launch_latent_assign(c, L, n, d_idx, d_latent, s, 1);
