@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void refrag16_k(const float* __restrict__ W, f
         dst[t] = scale * (transpose ? W[(ci * 16 + co) * KT + (KT - 1 - tap)] : W[(co * 16 + ci) * KT + tap]);
     }
 }
-// 16x16x4 fragments of conv_rows16_k: [tap][cb][mt][lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap]
-__global__ __launch_bounds__(256) void refrag16g_k(const float* __restrict__ W, float* __restrict__ dst, int COUT, int CIN, int KT)
+// 16x16x4 fragments of conv_rows16_k: [tap][cb][mt][lane][i] = Wsrc(co = 16mt + (lane&15), ci = 16cb + 4(lane>>4) + i, tap).
+// transpose = 0: Wsrc = W[co][ci][tap] (W is [COUT][CIN][KT]).  transpose = 1 (data-gradient conv, stride 1): W is [CIN][COUT][KT] and
+// Wsrc(co, ci, tap) = W[ci][co][KT-1-tap].
+__global__ __launch_bounds__(256) void refrag16g_k(const float* __restrict__ W, float* __restrict__ dst, int COUT, int CIN, int KT, int transpose, float scale)
 {
     const int CBN = CIN / 16, MTN = COUT / 16;
     const int total = KT * CBN * MTN * 256;
@@ -49,7 +51,8 @@ __global__ __launch_bounds__(256) void refrag16g_k(const float* __restrict__ W, 
         const int mt = r % MTN;
         r /= MTN;
         const int cb = r % CBN, tap = r / CBN;
-        dst[t] = W[((size_t)(16 * mt + (lane & 15)) * CIN + 16 * cb + 4 * (lane >> 4) + i) * KT + tap];
+        const int co = 16 * mt + (lane & 15), ci = 16 * cb + 4 * (lane >> 4) + i;
+        dst[t] = scale * (transpose ? W[((size_t)ci * COUT + co) * KT + (KT - 1 - tap)] : W[((size_t)co * CIN + ci) * KT + tap]);
     }
 }
 __global__ __launch_bounds__(64) void refrag_first_k(const float* __restrict__ W, float* __restrict__ dst)

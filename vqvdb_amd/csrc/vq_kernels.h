@@ -724,203 +724,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 }
 
 // ------------------------------------------------------------------------------------------
-// Row-blocked leaf-tile conv on the 32x32x2 MFMA for the encoder's 4^3-output layers with LDS-resident
-// weights (down 16->32 k4 s2; res_stack 32->32 k3): one step = (output row of SO positions along w,
-// valid (kd,kh)).  The SI input positions of the row are held in registers and every loaded position
-// feeds all the (ow,kw) pairs that touch it (3-4x fewer loads and table steps than one tap per step);
-// the pairs are walked input-position-major, which keeps every output's taps in ascending order, so
-// the arithmetic is identical to conv_mfma32_k.  Right after the last use of an input position the
-// same registers are re-loaded with the NEXT step's data (single rolling buffer, transformed in place).
-// ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int NW, int INMODE, int GIN, bool RESID, int GOUT, bool CSUM>
-__global__ __launch_bounds__(NW * 64, 2) void conv_rows32_k(ConvArgs A, const int4* __restrict__ steps)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    f32x4* lds = (f32x4*)smem_raw;
-    constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
-    constexpr int WTAP = NK * 64, NPI = SI * SI * SI, NPO = SO * SO * SO;
-    static_assert(INMODE == 0 || INMODE == 1, "raw or GroupNorm+ReLU input");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, q = lane >> 5;
-    const int tile = blockIdx.x * NW + wave;
-    const f32x4* wg4 = (const f32x4*)A.wfrag;
-    for (int i = threadIdx.x; i < A.n_taps * WTAP; i += NW * 64) lds[i] = wg4[i];
-    __syncthreads();
-    if (tile >= A.n_tiles) return;
-
-    float ta[INMODE == 1 ? NU : 1][4], tb[INMODE == 1 ? NU : 1][4];
-    if (INMODE == 1) {
-        constexpr int CPGI = CIN / (GIN > 0 ? GIN : 1);
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = 8 * u + 4 * q + i, g = c / CPGI;
-                const float mean = A.in_mean[((size_t)tile * GIN + g) * 32 + j];
-                const float rstd = A.in_rstd[((size_t)tile * GIN + g) * 32 + j];
-                ta[u][i] = rstd * A.in_gamma[c];
-                tb[u][i] = __builtin_fmaf(-mean, ta[u][i], A.in_beta[c]);
-            }
-    }
-    constexpr int NST = (GOUT > 0) ? NMT * 4 : 1;
-    GnAcc st[NST];
-#pragma unroll
-    for (int k = 0; k < NST; ++k) st[k].init();
-    float cs[CSUM ? NMT : 1][16];
-    if (CSUM) {
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cs[mt][r] = 0.0f;
-    }
-    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;
-    const f32x4* bf4 = (const f32x4*)A.bias_frag;
-    const int NS = A.n_steps;
-
-    int g0, g1;
-    split_range<SO * SO>(g0, g1);
-    int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
-    int4 e = steps[si];
-    int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
-    f32x4 xr[SI][NU];  // input row of the current step; re-loaded position by position for the next step
-#pragma unroll
-    for (int iw = 0; iw < SI; ++iw)
-#pragma unroll
-        for (int u = 0; u < NU; ++u) xr[iw][u] = in4[(size_t)(e.x + iw) * (CIN / 4) * 32 + u * 64];
-    for (int row = g0; row < g1; ++row) {
-        f32x16 acc[SO][NMT];
-#pragma unroll
-        for (int ow = 0; ow < SO; ++ow)
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ow][mt][r] = 0.0f;
-        bool last;
-        do {
-            if (INMODE == 1) {  // first use of the rolling buffer: waits for the loads issued during the previous step
-#pragma unroll
-                for (int iw = 0; iw < SI; ++iw)
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        f32x4 v = xr[iw][u];
-                        v.x = fmaxf(__builtin_fmaf(v.x, ta[u][0], tb[u][0]), 0.0f);
-                        v.y = fmaxf(__builtin_fmaf(v.y, ta[u][1], tb[u][1]), 0.0f);
-                        v.z = fmaxf(__builtin_fmaf(v.z, ta[u][2], tb[u][2]), 0.0f);
-                        v.w = fmaxf(__builtin_fmaf(v.w, ta[u][3], tb[u][3]), 0.0f);
-                        xr[iw][u] = v;
-                    }
-            }
-            const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
-            const f32x4* wl = lds + (size_t)e.y * WTAP + lane;  // e.y = first tap (kw = 0) of this (kd,kh)
-#pragma unroll
-            for (int iw = 0; iw < SI; ++iw) {
-#pragma unroll
-                for (int ow = 0; ow < SO; ++ow) {
-                    const int kw = iw - ow * STRIDE + PAD;
-                    if (kw < 0 || kw >= KS) continue;
-#pragma unroll
-                    for (int u = 0; u < NU; ++u)
-#pragma unroll
-                        for (int mt = 0; mt < NMT; ++mt) {
-                            const f32x4 a = wl[(size_t)kw * WTAP + (u * NMT + mt) * 64];
-                            acc[ow][mt] = mfma32(a.x, xr[iw][u].x, acc[ow][mt]);
-                            acc[ow][mt] = mfma32(a.y, xr[iw][u].y, acc[ow][mt]);
-                            acc[ow][mt] = mfma32(a.z, xr[iw][u].z, acc[ow][mt]);
-                            acc[ow][mt] = mfma32(a.w, xr[iw][u].w, acc[ow][mt]);
-                        }
-                }
-                // this input position is finished for the step: fetch the next step's (table index clamped)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) xr[iw][u] = in4[(size_t)(en.x + iw) * (CIN / 4) * 32 + u * 64];
-            }
-            last = (e.w & 2) != 0;
-            e = en;
-            en = en2;
-            ++si;
-        } while (!last);
-
-        // ---- epilogue for the SO output positions of this row (residual loads one position ahead) ----
-        f32x4 skn[RESID ? NMT : 1][4];
-        if (RESID) {
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    skn[mt][g] = ((const f32x4*)A.skip)[(((size_t)tile * NPO + row * SO) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j];
-        }
-#pragma unroll
-        for (int ow = 0; ow < SO; ++ow) {
-            const int po = row * SO + ow;
-            f32x4 skv[RESID ? NMT : 1][4];
-            if (RESID) {
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        skv[mt][g] = skn[mt][g];
-                        if (ow + 1 < SO)
-                            skn[mt][g] = ((const f32x4*)A.skip)[(((size_t)tile * NPO + po + 1) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j];
-                    }
-            }
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bias = bf4[(mt * 2 + q) * 4 + g];
-                    f32x4 v;
-                    v.x = acc[ow][mt][4 * g + 0] + bias.x;
-                    v.y = acc[ow][mt][4 * g + 1] + bias.y;
-                    v.z = acc[ow][mt][4 * g + 2] + bias.z;
-                    v.w = acc[ow][mt][4 * g + 3] + bias.w;
-                    const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
-                    if (RESID) {
-                        const f32x4 u = v * 0.1f;
-                        v = skv[mt][g] + u;
-                    }
-                    ((f32x4*)A.out)[o] = v;
-                    if (GOUT > 0) {
-                        st[mt * 4 + g].add(v.x);
-                        st[mt * 4 + g].add(v.y);
-                        st[mt * 4 + g].add(v.z);
-                        st[mt * 4 + g].add(v.w);
-                    }
-                    if (CSUM) {
-                        cs[mt][4 * g + 0] = cs[mt][4 * g + 0] + v.x;
-                        cs[mt][4 * g + 1] = cs[mt][4 * g + 1] + v.y;
-                        cs[mt][4 * g + 2] = cs[mt][4 * g + 2] + v.z;
-                        cs[mt][4 * g + 3] = cs[mt][4 * g + 3] + v.w;
-                    }
-                }
-        }
-    }
-    if (GOUT > 0) {
-        constexpr int CPGO = COUT / (GOUT > 0 ? GOUT : 1);
-        static_assert(GOUT == 0 || CPGO == 4, "row kernel: statistics groups of 4 channels (lane-local)");
-        const double inv_n = 1.0 / (double)(CPGO * NPO);
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float m, r;
-                gn_finish(st[mt * 4 + g].s, st[mt * 4 + g].q, inv_n, m, r);
-                const int grp = 8 * mt + 2 * g + q;
-                A.out_mean[((size_t)tile * GOUT + grp) * 32 + j] = m;
-                A.out_rstd[((size_t)tile * GOUT + grp) * 32 + j] = r;
-            }
-    }
-    if (CSUM) {
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q;
-                A.out_csum[((size_t)tile * COUT + co) * 32 + j] = cs[mt][r];
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Row-blocked leaf-tile conv on the 16x16x4 MFMA for every layer with a 4^3 output: the decoder's ResidualBlock(64) convs
 // (VQVAE_v2.py:190-210, :260), the encoder's ResidualBlock(32) convs (:240) and the down conv 16->32 k4 s2 (:239).
 // A wave owns a 16-leaf HALF tile and one output row of SO = 4 positions (SO x COUT/16 accumulators of 16 couts x 16 leaves);

@@ -291,7 +291,7 @@ std::vector<int> steps_conv(int SI, int SO, int KS, int STRIDE, int PAD, int KWG
             }
     return t;
 }
-// row schedule for conv_rows32_k: one step = (output row (od,oh) of SO positions, valid (kd,kh));
+// row schedule for conv_rows16_k: one step = (output row (od,oh) of SO positions, valid (kd,kh));
 // x = input row base position, y = first tap (kw = 0) of the (kd,kh) run, z = output row base
 std::vector<int> steps_rows(int SI, int SO, int KS, int STRIDE, int PAD)
 {
@@ -694,13 +694,8 @@ constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0,
 constexpr size_t LDS_ENC_DOWN_R = (size_t)64 * (1 * 2 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, resident
 constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 KB weight window
-constexpr size_t LDS_ENC_DOWN = (size_t)64 * (2 * 1 * 64) * 16;   // 128 KB, resident
-constexpr size_t LDS_ENC_R32 = (size_t)27 * (4 * 1 * 64) * 16;    // 108 KB, resident
-constexpr size_t LDS_DEC_R64 = (size_t)2 * (8 * 2 * 64) * 16;     // 2 x 16 KB
 constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 
-constexpr auto k_dec_r64c1_s = conv_mfma32_k<64, 64, 64, 64, 2, true, 1, 1, 8, false, 0, false, 0>;
-constexpr auto k_dec_r64c2_s = conv_mfma32_k<64, 64, 64, 64, 2, true, 1, 1, 8, true, 0, false, 0>;
 constexpr auto k_dec_tail_s = conv_mfma32_k<64, 128, 64, 4, 2, true, 1, 2, 0, false, 0, false, 2>;
 // position-split (small-batch) variants: 2 tiles per workgroup, no fused statistics
 
