@@ -142,7 +142,7 @@ int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
 /* Batches (per internal pass) of at most `tiles` 32-leaf tiles run the position-split kernels: each layer's output
  * slabs are spread over 4-8x more workgroups and the GroupNorm statistics are recomputed by sequential kernels, which
  * cuts the latency of small batches (the SOP default of 64 leaves, training batches of 2048) about 5x with bit-identical
- * results.  Default 640 tiles for encode (20480 leaves, the measured crossover) and 1.5x that for decode; 0 disables
+ * results.  Default 768 tiles for encode (24576 leaves, the measured crossover) and 1.25x that for decode; 0 disables
  * the split path. */
 int vqhip_set_small_batch_tiles(vqhip_codec* codec, int tiles);
 

@@ -77,7 +77,7 @@ struct vqhip_codec {
     std::string err;
     hipStream_t stream = nullptr;
     int64_t chunk = 65536;
-    int split_tiles = 640;   // batches of up to this many 32-leaf tiles (20480 leaves) take the position-split path
+    int split_tiles = 768;   // batches of up to this many 32-leaf tiles (24576 leaves) take the position-split path
 
     // device weights
     std::map<std::string, float*> dw;
@@ -930,7 +930,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
-    if (nt <= 3 * c->split_tiles / 2) return decode_chunk_split(c, L, d_idx, n, d_out, s);  // the decoder's crossover is about 1.5x the encoder's
+    if (nt <= 5 * c->split_tiles / 4) return decode_chunk_split(c, L, d_idx, n, d_out, s);  // the decoder's crossover is about 1.25x the encoder's (960 tiles)
     L.run("dec_stem", [&] {
         hipLaunchKernelGGL(stem_lut_k, dim3(g4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
                            (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
