@@ -139,11 +139,12 @@ int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_lea
  * (about 0.26 MB per leaf). */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
 
-/* Batches (per internal pass) of at most `tiles` 32-leaf tiles run the position-split kernels: each layer's output
- * slabs are spread over 4-8x more workgroups and the GroupNorm statistics are recomputed by sequential kernels, which
- * cuts the latency of small batches (the SOP default of 64 leaves, training batches of 2048) about 5x with bit-identical
- * results.  Default 768 tiles for encode (24576 leaves, the measured crossover) and 1.25x that for decode; 0 disables
- * the split path. */
+/* Small passes run the position-split kernels: each layer's output rows are spread over 4-16x more workgroups (the tiniest
+ * batches also split the output channels) and the GroupNorm statistics are recomputed by sequential kernels, which cuts the
+ * latency of small batches (the SOP default of 64 leaves, training batches of 2048) 10-20x with bit-identical results.
+ * Default (-1): automatic, from the measured crossovers — encode up to 832 tiles (26624 leaves) and 1025-1450 tiles, decode
+ * up to 1600 tiles; one wave per tile otherwise.  tiles >= 0 sets a plain threshold instead (encode `tiles`, decode 1.25x);
+ * 0 disables the split path. */
 int vqhip_set_small_batch_tiles(vqhip_codec* codec, int tiles);
 
 /* Allocates up front what calls of up to n_leaves leaves (capped at the chunk size) need: the device workspace,

@@ -223,7 +223,7 @@ def test_gradients_do_not_depend_on_the_launch_path(weights):
     x = synth.make_leaves(96, seed=6100)
     a, b = HipCodec(weightpack.dumps(weights)), HipCodec(weightpack.dumps(weights))
     a.fulltrain_begin(), b.fulltrain_begin()
-    b.set_small_batch_tiles(0)                       # b: classic encoder path (what batches > 20480 leaves use)
+    b.set_small_batch_tiles(0)                       # b: classic encoder path (what large batches use)
     ga, gb = _hip_grads(a, weights, x), _hip_grads(b, weights, x)
     for k in ga:
         assert np.array_equal(ga[k], gb[k]), k

@@ -318,10 +318,11 @@ def test_in_process_multi_device_sharding(codec, pack):
     m.close()
 
 
-@pytest.mark.parametrize("n", [1, 64, 100, 1024, 2048])
+@pytest.mark.parametrize("n", [1, 64, 100, 300, 1024, 2048, 20000])
 def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
-    """Position-split kernels + sequential statistics (default for <= 640 tiles) against the one-wave-per-tile path
-    and the oracle: indices, every stored intermediate and voxels identical."""
+    """Position-split kernels + sequential statistics (default for <= 768 tiles; the tiniest batches additionally split the output
+    channels of the 4^3 convs and of the folded tail over gridDim.z) against the one-wave-per-tile path and the oracle: indices,
+    every stored intermediate and voxels identical."""
     leaves = synth.make_leaves(n, seed=900 + n)
     a, b = HipCodec(pack), HipCodec(pack)
     b.set_small_batch_tiles(0)                      # b: classic path

@@ -347,9 +347,11 @@ class HipCodec:
         self._check(self._lib.vqhip_train_commit(self._h))
 
     def set_small_batch_tiles(self, tiles: int):
+        """-1: automatic choice between the position-split and the one-wave-per-tile path (default); 0: never split;
+        n > 0: split passes of up to n tiles (encode) / 1.25 n (decode)."""
         self._check(self._lib.vqhip_set_small_batch_tiles(self._h, tiles))
 
-    # ---- full training step (stage 2, in progress) ----
+    # ---- full training step (stage 2) ----
     def fulltrain_begin(self):
         self._check(self._lib.vqhip_fulltrain_begin(self._h))
 

@@ -488,15 +488,21 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
 //            the caller's leaf-major [n][512] buffer (VQVAECodec.cpp:182-192).
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int NPI, int NPO, int NW, bool STREAM, int KWG, int INMODE, int GIN, bool RESID, int GOUT,
-          bool CSUM, int OUTMODE>
+          bool CSUM, int OUTMODE, int MSPLIT = 1>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
     constexpr int WTAP = NK * 64;            // float4 per tap
-    constexpr int PIECES = WTAP / (NW * 64); // 1 KiB pieces per wave per streamed tap
-    static_assert(!STREAM || (WTAP % (NW * 64) == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
+    // MSPLIT > 1 (small batches): blockIdx.z selects NML of the NMT 32-cout tiles, so a wave's serial MFMA chain is MSPLIT times
+    // shorter; every output keeps its K order.  Only the needed weight pieces are streamed, packed densely in the LDS window.
+    constexpr int NML = NMT / MSPLIT, NKL = NU * NML, WTAPL = NKL * 64;
+    static_assert(STREAM || MSPLIT == 1, "cout split only for streamed weights");
+    constexpr int PIECES = NKL / NW;         // 1 KiB pieces per wave per streamed tap
+    static_assert(!STREAM || (NKL % NW == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
+    static_assert(NMT % MSPLIT == 0 && (MSPLIT == 1 || (GOUT == 0 && !CSUM && !RESID)), "cout split: plain epilogue only");
+    const int mz = MSPLIT > 1 ? blockIdx.z * NML : 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, q = lane >> 5;
@@ -566,14 +572,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     if (STREAM) {
 #pragma unroll
         for (int pc = 0; pc < PIECES; ++pc) {
-            const int piece = wave * PIECES + pc;
-            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAP + piece * 64);
+            const int t = wave * PIECES + pc, piece = (t / NML) * NMT + mz + t % NML;
+            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAPL + t * 64);
         }
     }
     for (int po = g0; po < g1; ++po) {
-        f32x16 acc[NMT];
+        f32x16 acc[NML];
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
+        for (int mt = 0; mt < NML; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
         bool last;
@@ -594,24 +600,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 for (int u = 0; u < NU; ++u) bn[k][u] = in4[(size_t)ipn * (CIN / 4) * 32 + u * 64];
             }
             if (STREAM) {
-                f32x4* dst = lds + ((si + 1) & 1) * WTAP;
+                f32x4* dst = lds + ((si + 1) & 1) * WTAPL;
 #pragma unroll
                 for (int pc = 0; pc < PIECES; ++pc) {
-                    const int piece = wave * PIECES + pc;
-                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
+                    const int t = wave * PIECES + pc, piece = (t / NML) * NMT + mz + t % NML;
+                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + t * 64);
                 }
             }
 #pragma unroll
             for (int kg = 0; kg < KWG; ++kg) {
                 if (kg < (e.w >> 8)) {
-                    const f32x4* wl = (STREAM ? lds + (si & 1) * WTAP : lds + (size_t)(e.y + kg) * WTAP) + lane;
+                    const f32x4* wl = (STREAM ? lds + (si & 1) * WTAPL : lds + (size_t)(e.y + kg) * WTAP) + lane;
                     f32x4 a_nx = wl[0];
                     f32x4 b;
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        const int u = k / NMT, mt = k % NMT;
+                    for (int k = 0; k < NKL; ++k) {
+                        const int u = k / NML, mt = k % NML;
                         const f32x4 a = a_nx;
-                        if (k + 1 < NK) a_nx = wl[(k + 1) * 64];  // LDS A-fragment one group ahead of its MFMAs
+                        if (k + 1 < NKL) a_nx = wl[(k + 1) * 64];  // LDS A-fragment one group ahead of its MFMAs
                         if (mt == 0) {
                             b = bc[kg][u];
                             if (INMODE == 1) {
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
         } while (!last);
 
         // ---- epilogue for output position po ----
-        f32x4 skv[RESID ? NMT : 1][4];
+        f32x4 skv[RESID ? NML : 1][4];
         if (RESID) {  // issue all residual loads before any of the epilogue math
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
@@ -649,15 +655,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     skv[mt][g] = ((const f32x4*)A.skip)[(((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j];
         }
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
+        for (int ml = 0; ml < NML; ++ml) {
+            const int mt = mz + ml;   // global 32-cout tile
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bias = bf4[((OUTMODE == 2 ? po * NMT : 0) + mt) * 8 + q * 4 + g];
                 f32x4 v;
-                v.x = acc[mt][4 * g + 0] + bias.x;
-                v.y = acc[mt][4 * g + 1] + bias.y;
-                v.z = acc[mt][4 * g + 2] + bias.z;
-                v.w = acc[mt][4 * g + 3] + bias.w;
+                v.x = acc[ml][4 * g + 0] + bias.x;
+                v.y = acc[ml][4 * g + 1] + bias.y;
+                v.z = acc[ml][4 * g + 2] + bias.z;
+                v.w = acc[ml][4 * g + 3] + bias.w;
                 // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
                 const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
                 if (RESID) {
@@ -736,13 +743,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 // 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false>
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1>
 __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int CBN = CIN / 16, MTN = COUT / 16, NPI = SI * SI * SI, NPO = SO * SO * SO;
     constexpr int WTAP = CBN * MTN * 64, WSTEP = KS * WTAP;   // float4 per tap / per step (KS kw taps)
+    // MSPLIT > 1 (small batches): blockIdx.z selects MTL of the MTN 16-cout blocks, so a wave's serial MFMA chain is MSPLIT times
+    // shorter; the K order of every output is unchanged.  Only the needed weight pieces are staged, packed densely in LDS.
+    constexpr int MTL = MTN / MSPLIT, WTAPL = WTAP / MSPLIT, WSTEPL = WSTEP / MSPLIT;
+    static_assert(MTN % MSPLIT == 0 && (MSPLIT == 1 || (GOUT == 0 && !CSUM)), "cout split: no fused statistics");
+    const int mz = MSPLIT > 1 ? blockIdx.z * MTL : 0;
     static_assert(INMODE == 0 || INMODE == 1, "raw or GroupNorm(8)+ReLU input");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -787,17 +799,23 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
 #pragma unroll
         for (int cb = 0; cb < CBN; ++cb) xr[iw][cb] = in4[((size_t)(e.x + iw) * (CIN / 4) + 4 * cb) * 32];
     if (RESIDENT) {   // all taps of the layer stay in LDS (A.n_taps x WTAP float4): no per-step barrier
-        for (int i = threadIdx.x; i < A.n_taps * WTAP; i += 512) lds[i] = wg4[i];
+        for (int i = threadIdx.x; i < A.n_taps * WTAPL; i += 512) {
+            const int t = i >> 6;
+            lds[i] = MSPLIT == 1 ? wg4[i] : wg4[(size_t)((t / MTL) * MTN + mz + t % MTL) * 64 + (i & 63)];
+        }
         __syncthreads();
     } else {
-        for (int piece = wave; piece < WSTEP / 64; piece += 8) glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEP + piece * 64);
+        for (int t = wave; t < WSTEPL / 64; t += 8) {
+            const int piece = (t / MTL) * MTN + mz + t % MTL;
+            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEPL + t * 64);
+        }
     }
     for (int row = g0; row < g1; ++row) {
-        f32x4 acc[SO][MTN];
+        f32x4 acc[SO][MTL];
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow)
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         bool last;
         do {
             if (INMODE == 1) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
@@ -817,10 +835,13 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
             if (!RESIDENT) {
                 __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight pieces and input row have landed
                 __syncthreads();                      // every wave's pieces of W(step) landed; every wave done reading W(step-1)
-                f32x4* dst = lds + ((si + 1) & 1) * WSTEP;
-                for (int piece = wave; piece < WSTEP / 64; piece += 8) glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
+                f32x4* dst = lds + ((si + 1) & 1) * WSTEPL;
+                for (int t = wave; t < WSTEPL / 64; t += 8) {
+                    const int piece = (t / MTL) * MTN + mz + t % MTL;
+                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + t * 64);
+                }
             }
-            const f32x4* wl = (RESIDENT ? lds + (size_t)e.y * WTAP : lds + (si & 1) * WSTEP) + lane;
+            const f32x4* wl = (RESIDENT ? lds + (size_t)e.y * WTAPL : lds + (si & 1) * WSTEPL) + lane;
 #pragma unroll
             for (int iw = 0; iw < SI; ++iw) {
 #pragma unroll
@@ -829,17 +850,17 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
                     if (kw < 0 || kw >= KS) continue;
 #pragma unroll
                     for (int cb = 0; cb < CBN; ++cb) {
-                        f32x4 a[MTN];   // the cout tiles of this (tap, channel block): MTN LDS reads ahead of their MFMAs, no further
+                        f32x4 a[MTL];   // the cout tiles of this (tap, channel block): MTN LDS reads ahead of their MFMAs, no further
 #pragma unroll
-                        for (int mt = 0; mt < MTN; ++mt) a[mt] = wl[((kw * CBN + cb) * MTN + mt) * 64];
+                        for (int mt = 0; mt < MTL; ++mt) a[mt] = wl[((kw * CBN + cb) * MTL + mt) * 64];
 #pragma unroll
-                        for (int mt = 0; mt < MTN; ++mt) {
+                        for (int mt = 0; mt < MTL; ++mt) {
                             acc[ow][mt] = mfma16(a[mt].x, xr[iw][cb].x, acc[ow][mt]);
                             acc[ow][mt] = mfma16(a[mt].y, xr[iw][cb].y, acc[ow][mt]);
                             acc[ow][mt] = mfma16(a[mt].z, xr[iw][cb].z, acc[ow][mt]);
                             acc[ow][mt] = mfma16(a[mt].w, xr[iw][cb].w, acc[ow][mt]);
                         }
-                        if (MTN >= 4) __builtin_amdgcn_sched_barrier(0);
+                        if (MTL >= 4) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
@@ -854,19 +875,19 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow) {
             const size_t o = ((size_t)(row * SO + ow) * (COUT / 4)) * 32;
-            f32x4 sk[RESID ? MTN : 1];
+            f32x4 sk[RESID ? MTL : 1];
             if (RESID) {
 #pragma unroll
-                for (int mt = 0; mt < MTN; ++mt) sk[mt] = skip4[o + (size_t)4 * mt * 32];
+                for (int mt = 0; mt < MTL; ++mt) sk[mt] = skip4[o + (size_t)4 * (mz + mt) * 32];
             }
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt) {
-                f32x4 v = acc[ow][mt] + bias4[4 * mt + q4];
+            for (int mt = 0; mt < MTL; ++mt) {
+                f32x4 v = acc[ow][mt] + bias4[4 * (mz + mt) + q4];
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
                     v = sk[mt] + u;
                 }
-                if (active) out4[o + (size_t)4 * mt * 32] = v;
+                if (active) out4[o + (size_t)4 * (mz + mt) * 32] = v;
                 if (GOUT > 0) {
                     st[mt].add(v.x);
                     st[mt].add(v.y);

@@ -77,7 +77,7 @@ struct vqhip_codec {
     std::string err;
     hipStream_t stream = nullptr;
     int64_t chunk = 65536;
-    int split_tiles = 768;   // batches of up to this many 32-leaf tiles (24576 leaves) take the position-split path
+    int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
     // device weights
     std::map<std::string, float*> dw;
@@ -696,7 +696,14 @@ constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, r
 constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 KB weight window
 constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 
-constexpr auto k_dec_tail_s = conv_mfma32_k<64, 128, 64, 4, 2, true, 1, 2, 0, false, 0, false, 2>;
+// position-split variants that additionally split the output channels over gridDim.z (a wave's serial MFMA chain is the latency
+// of a small batch): the folded tail always (4 slabs x 4 voxel blocks), the 4^3 convs for the tiniest batches
+constexpr auto k_dec_tail_s4 = conv_mfma32_k<64, 128, 64, 4, 2, true, 1, 2, 0, false, 0, false, 2, 4>;
+constexpr auto k_dec_r64c1_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false, false, 4>;
+constexpr auto k_dec_r64c2_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false, false, 4>;
+constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true, 2>;
+constexpr auto k_enc_r32c1_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 0, false, true, 2>;
+constexpr auto k_enc_r32c2_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, false, true, 2>;
 // position-split (small-batch) variants: 2 tiles per workgroup, no fused statistics
 
 constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + projection A-fragments (144 KB)
@@ -744,6 +751,16 @@ int split_factor(int wgs, int lo, int n_groups, int target)
     return std::min(ps, n_groups);
 }
 
+// Which path a pass of nt 32-leaf tiles takes.  One wave per tile fills the chip in rounds of 1024 tiles (1024 SIMDs), so its
+// time is a staircase (encode: 6.4 ms at 1024 tiles, 10.0 ms at 1056); the split path is linear (about 6.8 us per tile) and
+// wins below the first step and again just above it.  Crossovers measured with tools/small_batch_probe.py.
+bool use_split(const vqhip_codec* c, int nt, bool decode)
+{
+    if (c->split_tiles >= 0) return nt <= (decode ? 5 * c->split_tiles / 4 : c->split_tiles);
+    if (decode) return nt <= 1600;
+    return nt <= 832 || (nt > 1024 && nt <= 1450);
+}
+
 // Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
 // od-slabs split over gridDim.y workgroups, activations are stored, and the GroupNorm / channel-sum statistics are
 // recomputed by sequential kernels in the contract's order.  Same results bit for bit, ~5x lower latency.
@@ -780,7 +797,11 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         ConvArgs A{};
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.grp_start = od("steps.rows_k4s2_8");
-        L.run("enc_down_s", [&] { hipLaunchKernelGGL(k_enc_down_rs, dim3(gh, split_factor(gh, 4, 16, 512)), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
+        const int psr = split_factor(gh, 4, 16, 512);
+        L.run("enc_down_s", [&] {
+            if (gh * psr * 2 <= 256) hipLaunchKernelGGL(k_enc_down_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_DOWN_R / 2, s, A, (const int4*)w["steps.rows_k4s2_8"]);
+            else hipLaunchKernelGGL(k_enc_down_rs, dim3(gh, psr), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]);
+        });
         L.run("enc_stats_x7", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_x7"], a["st_b.mean"], a["st_b.rstd"]); });
     }
     {
@@ -788,11 +809,19 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w16"], A.bias_frag = w["r32c1.braw"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
-        L.run("enc_res32_conv1_s", [&] { hipLaunchKernelGGL(k_enc_r32c1_rs, dim3(gh, split_factor(gh, 4, 16, 512)), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        const int psr = split_factor(gh, 4, 16, 512);
+        const bool ms = gh * psr * 2 <= 256;   // up to 1024 leaves (measured): also split the 32 couts over gridDim.z
+        L.run("enc_res32_conv1_s", [&] {
+            if (ms) hipLaunchKernelGGL(k_enc_r32c1_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else hipLaunchKernelGGL(k_enc_r32c1_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
+        });
         L.run("enc_stats_y9", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_y9"], a["st_a.mean"], a["st_a.rstd"]); });
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w16"], A.bias_frag = w["r32c2.braw"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
-        L.run("enc_res32_conv2_s", [&] { hipLaunchKernelGGL(k_enc_r32c2_rs, dim3(gh, split_factor(gh, 4, 16, 512)), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv2_s", [&] {
+            if (ms) hipLaunchKernelGGL(k_enc_r32c2_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else hipLaunchKernelGGL(k_enc_r32c2_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
+        });
         L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"]); });
     }
     if (d_latent) {
@@ -817,7 +846,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
     L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt), dim3(256), 0, s, d_leaves, a["xt"], n); });
-    if (nt <= c->split_tiles) return encode_chunk_split(c, L, n, d_idx, s, d_latent);
+    if (use_split(c, nt, false)) return encode_chunk_split(c, L, n, d_idx, s, d_latent);
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
@@ -903,11 +932,18 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.wfrag = w["r64c1.w16"], A.bias_frag = w["r64c1.braw"];
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
         const int gh = (2 * nt + 7) / 8, psr = split_factor(gh, 4, 16, 512);   // 8 half tiles per workgroup, 16 output rows to split
-        L.run("dec_res64_conv1_s", [&] { hipLaunchKernelGGL(k_dec_r64c1_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        const bool ms = gh * psr * 4 <= 1024;   // up to 2048 leaves (measured): also split the 64 couts over gridDim.z
+        L.run("dec_res64_conv1_s", [&] {
+            if (ms) hipLaunchKernelGGL(k_dec_r64c1_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else hipLaunchKernelGGL(k_dec_r64c1_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
+        });
         L.run("dec_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_y4"], a["st_a.mean"], a["st_a.rstd"]); });
         A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w16"], A.bias_frag = w["r64c2.braw"], A.skip = a["d_d2"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
-        L.run("dec_res64_conv2_s", [&] { hipLaunchKernelGGL(k_dec_r64c2_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("dec_res64_conv2_s", [&] {
+            if (ms) hipLaunchKernelGGL(k_dec_r64c2_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else hipLaunchKernelGGL(k_dec_r64c2_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
+        });
         L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"]); });
     }
     {
@@ -915,7 +951,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
-        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(k_dec_tail_s, dim3(g2, 4), dim3(128), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
+        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(k_dec_tail_s4, dim3(g2, 4, 4), dim3(128), LDS_DEC_TAIL / 4, s, A, (const int4*)w["steps.tail"]); });
     }
     return L.rc;
 }
@@ -930,7 +966,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
-    if (nt <= 5 * c->split_tiles / 4) return decode_chunk_split(c, L, d_idx, n, d_out, s);  // the decoder's crossover is about 1.25x the encoder's (960 tiles)
+    if (use_split(c, nt, true)) return decode_chunk_split(c, L, d_idx, n, d_out, s);
     L.run("dec_stem", [&] {
         hipLaunchKernelGGL(stem_lut_k, dim3(g4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
                            (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
@@ -1309,7 +1345,7 @@ int vqhip_set_chunk_leaves(vqhip_codec* c, int64_t chunk)
 int vqhip_set_small_batch_tiles(vqhip_codec* c, int tiles)
 {
     if (!c) return VQHIP_ERR_INVALID;
-    if (tiles < 0) return fail(c, VQHIP_ERR_INVALID, "small_batch_tiles must be >= 0");
+    if (tiles < -1) return fail(c, VQHIP_ERR_INVALID, "small_batch_tiles must be >= 0, or -1 for the automatic choice");
     c->split_tiles = tiles;
     return VQHIP_OK;
 }
