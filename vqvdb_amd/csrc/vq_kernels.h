@@ -488,21 +488,15 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
 //            the caller's leaf-major [n][512] buffer (VQVAECodec.cpp:182-192).
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int NPI, int NPO, int NW, bool STREAM, int KWG, int INMODE, int GIN, bool RESID, int GOUT,
-          bool CSUM, int OUTMODE, int MSPLIT = 1>
+          bool CSUM, int OUTMODE>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
     constexpr int WTAP = NK * 64;            // float4 per tap
-    // MSPLIT > 1 (small batches): blockIdx.z selects NML of the NMT 32-cout tiles, so a wave's serial MFMA chain is MSPLIT times
-    // shorter; every output keeps its K order.  Only the needed weight pieces are streamed, packed densely in the LDS window.
-    constexpr int NML = NMT / MSPLIT, NKL = NU * NML, WTAPL = NKL * 64;
-    static_assert(STREAM || MSPLIT == 1, "cout split only for streamed weights");
-    constexpr int PIECES = NKL / NW;         // 1 KiB pieces per wave per streamed tap
-    static_assert(!STREAM || (NKL % NW == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
-    static_assert(NMT % MSPLIT == 0 && (MSPLIT == 1 || (GOUT == 0 && !CSUM && !RESID)), "cout split: plain epilogue only");
-    const int mz = MSPLIT > 1 ? blockIdx.z * NML : 0;
+    constexpr int PIECES = WTAP / (NW * 64); // 1 KiB pieces per wave per streamed tap
+    static_assert(!STREAM || (WTAP % (NW * 64) == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, q = lane >> 5;
@@ -572,14 +566,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     if (STREAM) {
 #pragma unroll
         for (int pc = 0; pc < PIECES; ++pc) {
-            const int t = wave * PIECES + pc, piece = (t / NML) * NMT + mz + t % NML;
-            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAPL + t * 64);
+            const int piece = wave * PIECES + pc;
+            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAP + piece * 64);
         }
     }
     for (int po = g0; po < g1; ++po) {
-        f32x16 acc[NML];
+        f32x16 acc[NMT];
 #pragma unroll
-        for (int mt = 0; mt < NML; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
         bool last;
@@ -600,24 +594,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 for (int u = 0; u < NU; ++u) bn[k][u] = in4[(size_t)ipn * (CIN / 4) * 32 + u * 64];
             }
             if (STREAM) {
-                f32x4* dst = lds + ((si + 1) & 1) * WTAPL;
+                f32x4* dst = lds + ((si + 1) & 1) * WTAP;
 #pragma unroll
                 for (int pc = 0; pc < PIECES; ++pc) {
-                    const int t = wave * PIECES + pc, piece = (t / NML) * NMT + mz + t % NML;
-                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + t * 64);
+                    const int piece = wave * PIECES + pc;
+                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
                 }
             }
 #pragma unroll
             for (int kg = 0; kg < KWG; ++kg) {
                 if (kg < (e.w >> 8)) {
-                    const f32x4* wl = (STREAM ? lds + (si & 1) * WTAPL : lds + (size_t)(e.y + kg) * WTAP) + lane;
+                    const f32x4* wl = (STREAM ? lds + (si & 1) * WTAP : lds + (size_t)(e.y + kg) * WTAP) + lane;
                     f32x4 a_nx = wl[0];
                     f32x4 b;
 #pragma unroll
-                    for (int k = 0; k < NKL; ++k) {
-                        const int u = k / NML, mt = k % NML;
+                    for (int k = 0; k < NK; ++k) {
+                        const int u = k / NMT, mt = k % NMT;
                         const f32x4 a = a_nx;
-                        if (k + 1 < NKL) a_nx = wl[(k + 1) * 64];  // LDS A-fragment one group ahead of its MFMAs
+                        if (k + 1 < NK) a_nx = wl[(k + 1) * 64];  // LDS A-fragment one group ahead of its MFMAs
                         if (mt == 0) {
                             b = bc[kg][u];
                             if (INMODE == 1) {
@@ -646,7 +640,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
         } while (!last);
 
         // ---- epilogue for output position po ----
-        f32x4 skv[RESID ? NML : 1][4];
+        f32x4 skv[RESID ? NMT : 1][4];
         if (RESID) {  // issue all residual loads before any of the epilogue math
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
@@ -655,16 +649,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     skv[mt][g] = ((const f32x4*)A.skip)[(((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j];
         }
 #pragma unroll
-        for (int ml = 0; ml < NML; ++ml) {
-            const int mt = mz + ml;   // global 32-cout tile
+        for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bias = bf4[((OUTMODE == 2 ? po * NMT : 0) + mt) * 8 + q * 4 + g];
                 f32x4 v;
-                v.x = acc[ml][4 * g + 0] + bias.x;
-                v.y = acc[ml][4 * g + 1] + bias.y;
-                v.z = acc[ml][4 * g + 2] + bias.z;
-                v.w = acc[ml][4 * g + 3] + bias.w;
+                v.x = acc[mt][4 * g + 0] + bias.x;
+                v.y = acc[mt][4 * g + 1] + bias.y;
+                v.z = acc[mt][4 * g + 2] + bias.z;
+                v.w = acc[mt][4 * g + 3] + bias.w;
                 // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
                 const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
                 if (RESID) {
@@ -727,6 +720,84 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q;
                 A.out_csum[((size_t)tile * COUT + co) * 32 + j] = cs[mt][r];
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Folded decoder tail for small batches (position-split path): one wave = (tile, output slab d, block mb of 32 voxels), the
+// four blocks of a slab in one workgroup (their activation loads hit the same lines).  Same fragments (tail.w, tail.b) and the
+// same accumulation order per output as conv_mfma32_k<OUTMODE 2>: input positions of the slab's receptive field ascending,
+// channels in P8 order.  A lone wave has nobody to hide its load latency behind, so there is no LDS window and no barrier:
+// weights and activations of two consecutive positions live in two register sets, each refilled for position p+2 right after
+// its last MFMA has issued (64-leaf decode: the LDS-window variant spent 3 us per 0.85 us of MFMAs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void tail_small_k(ConvArgs A)   // 2 waves/SIMD: room for both register sets
+{
+    constexpr int CIN = 64, NU = 8, NMT = 4, NPI = 64;
+    const int lane = threadIdx.x & 63;
+    const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, q = lane >> 5;
+    const int tile = blockIdx.x, d = blockIdx.y;
+    const int p0 = (d > 2 ? d - 2 : 0) * 16, p1 = ((d + 2 < 3 ? d + 2 : 3) + 1) * 16;   // an even number of positions (48 or 64)
+    const int sbase = d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176;                      // first step of slab d in tail.w
+    float ta[NU][4];
+    {
+        float hid[CIN / 4], gall[CIN];
+        se_hidden<CIN>(A.se_csum + (size_t)tile * CIN * 32 + j, A.se_fc0, hid);
+        se_gates<CIN>(hid, A.se_fc2, gall);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ta[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
+    }
+    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;       // + p*(CIN/4)*32 + u*64
+    const f32x4* w4 = (const f32x4*)A.wfrag + ((size_t)(sbase - p0) * NU * NMT + mb) * 64 + lane;   // + (p*NU*NMT + u*NMT)*64
+    f32x4 w[2][NU], b[2][NU];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            w[h][u] = w4[((size_t)(p0 + h) * NU + u) * NMT * 64];
+            b[h][u] = in4[(size_t)(p0 + h) * (CIN / 4) * 32 + u * 64];
+        }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int p = p0; p < p1; p += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int pn = p + h + 2 < p1 ? p + h + 2 : p + h;   // the last pair re-requests valid data
+            asm volatile("" : "+s"(pn));   // opaque: otherwise the optimiser replaces the loop-carried prefetch by a load at the point of use
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const f32x4 a = w[h][u];
+                f32x4 x = b[h][u];
+                x.x = x.x * ta[u][0];
+                x.y = x.y * ta[u][1];
+                x.z = x.z * ta[u][2];
+                x.w = x.w * ta[u][3];
+                acc = mfma32(a.x, x.x, acc);
+                acc = mfma32(a.y, x.y, acc);
+                acc = mfma32(a.z, x.z, acc);
+                acc = mfma32(a.w, x.w, acc);
+                w[h][u] = w4[((size_t)pn * NU + u) * NMT * 64];
+                b[h][u] = in4[(size_t)pn * (CIN / 4) * 32 + u * 64];
+                __builtin_amdgcn_sched_barrier(0);   // issue the refill here, not where the scheduler would like it (next to its use)
+            }
+        }
+    }
+    const f32x4* bf4 = (const f32x4*)A.bias_frag;
+    const int64_t leaf = (int64_t)tile * 32 + j;
+    if (leaf >= A.n_leaves) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bias = bf4[(d * NMT + mb) * 8 + q * 4 + g];
+        f32x4 sg;
+        sg.x = vq_sigmoid(acc[4 * g + 0] + bias.x);
+        sg.y = vq_sigmoid(acc[4 * g + 1] + bias.y);
+        sg.z = vq_sigmoid(acc[4 * g + 2] + bias.z);
+        sg.w = vq_sigmoid(acc[4 * g + 3] + bias.w);
+        *(f32x4*)(A.out + leaf * 512 + d * 128 + 32 * mb + 8 * g + 4 * q) = sg;   // 4 consecutive voxels of this lane's leaf
     }
 }
 
@@ -1164,13 +1235,26 @@ __global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __rest
     GnAcc st[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) st[k].init();
-#pragma unroll 8
-    for (int p = 0; p < NP; ++p) {
-        const f32x4 v = in4[(size_t)p * (C / 4) * 32];
-        st[0].add(v.x);
-        st[0].add(v.y);
-        st[CPG == 2 ? 1 : 0].add(v.z);
-        st[CPG == 2 ? 1 : 0].add(v.w);
+    // latency-bound twice over (one dependent fp64 chain; a lone wave's loads): keep 32 loads in flight ahead of the chain
+    constexpr int NB = 32;
+    static_assert(NP % NB == 0, "positions in batches of 32");
+    f32x4 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = in4[(size_t)k * (C / 4) * 32];
+    for (int p0 = 0; p0 < NP; p0 += NB) {
+        f32x4 u[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) u[k] = v[k];
+        const int pn = p0 + NB < NP ? p0 + NB : p0;   // last batch: re-request valid data
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = in4[(size_t)(pn + k) * (C / 4) * 32];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            st[0].add(u[k].x);
+            st[0].add(u[k].y);
+            st[CPG == 2 ? 1 : 0].add(u[k].z);
+            st[CPG == 2 ? 1 : 0].add(u[k].w);
+        }
     }
     constexpr int G = C / CPG;
     if (CPG == 8) {  // group = this wave's two quads: low-quad partial + high-quad partial

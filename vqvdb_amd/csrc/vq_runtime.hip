@@ -697,8 +697,7 @@ constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 K
 constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 
 // position-split variants that additionally split the output channels over gridDim.z (a wave's serial MFMA chain is the latency
-// of a small batch): the folded tail always (4 slabs x 4 voxel blocks), the 4^3 convs for the tiniest batches
-constexpr auto k_dec_tail_s4 = conv_mfma32_k<64, 128, 64, 4, 2, true, 1, 2, 0, false, 0, false, 2, 4>;
+// of a small batch): the 4^3 convs for the tiniest batches; the folded tail has its own small-batch kernel (tail_small_k)
 constexpr auto k_dec_r64c1_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false, false, 4>;
 constexpr auto k_dec_r64c2_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false, false, 4>;
 constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true, 2>;
@@ -757,7 +756,7 @@ int split_factor(int wgs, int lo, int n_groups, int target)
 bool use_split(const vqhip_codec* c, int nt, bool decode)
 {
     if (c->split_tiles >= 0) return nt <= (decode ? 5 * c->split_tiles / 4 : c->split_tiles);
-    if (decode) return nt <= 1600;
+    if (decode) return nt <= 1700;
     return nt <= 832 || (nt > 1024 && nt <= 1450);
 }
 
@@ -951,7 +950,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
-        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(k_dec_tail_s4, dim3(g2, 4, 4), dim3(128), LDS_DEC_TAIL / 4, s, A, (const int4*)w["steps.tail"]); });
+        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small_k, dim3(nt, 4), dim3(256), 0, s, A); });
     }
     return L.rc;
 }
