@@ -831,6 +831,9 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int half = blockIdx.x * 8 + wave;
     const bool active = (half >> 1) < A.n_tiles;
+    // waves past the last half tile only help staging the weights; in the launches without fused statistics (small batches: a
+    // workgroup may hold 1 live wave and 7 idle ones) they also stay off the MFMA pipe their live neighbours need
+    const bool work = (GOUT > 0 || CSUM) ? true : active;
     if (!active) half = 2 * A.n_tiles - 1;
     const int tile = half >> 1;
     const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
             for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         bool last;
         do {
-            if (INMODE == 1) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
+            if (INMODE == 1 && work) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
 #pragma unroll
                 for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
@@ -913,6 +916,7 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
                 }
             }
             const f32x4* wl = (RESIDENT ? lds + (size_t)e.y * WTAPL : lds + (si & 1) * WSTEPL) + lane;
+            if (work)
 #pragma unroll
             for (int iw = 0; iw < SI; ++iw) {
 #pragma unroll
