@@ -318,10 +318,10 @@ def test_in_process_multi_device_sharding(codec, pack):
     m.close()
 
 
-@pytest.mark.parametrize("n", [1, 64, 100, 300, 1024, 2048, 20000])
+@pytest.mark.parametrize("n", [1, 64, 100, 300, 1024, 2048, 20000, 40000])
 def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
-    """Position-split kernels + sequential statistics (default for <= 768 tiles; the tiniest batches additionally split the output
-    channels of the 4^3 convs and of the folded tail over gridDim.z) against the one-wave-per-tile path and the oracle: indices,
+    """Position-split kernels + sequential statistics (default policy: encode <= 832 tiles and 1025-1450 tiles, decode <= 1700 tiles;
+    the tiniest batches additionally split the output channels of the 4^3 convs, the folded tail has its own small-batch kernel) against the one-wave-per-tile path and the oracle: indices,
     every stored intermediate and voxels identical."""
     leaves = synth.make_leaves(n, seed=900 + n)
     a, b = HipCodec(pack), HipCodec(pack)
@@ -329,7 +329,7 @@ def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
     a.debug_enable(True), b.debug_enable(True)
     ia, ib = a.encode(leaves), b.encode(leaves)
     assert np.array_equal(ia, ib)
-    for name in ("e_a1", "e_y4", "e_a6", "e_x7", "e_y9", "e_x11"):
+    for name in ("e_a1", "e_y4", "e_a6", "e_x7", "e_y9", "e_x11") if n <= 20000 else ("e_x7", "e_x11"):
         c, p = DEBUG_SHAPES[name]
         assert np.array_equal(_bits(a.debug_fetch(name, n, c, p)), _bits(b.debug_fetch(name, n, c, p))), name
     if n <= 1024:
