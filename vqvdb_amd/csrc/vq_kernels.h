@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1>
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false>
 __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -868,10 +868,14 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
     int4 e = steps[si];
     int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
     f32x4 xr[SI][CBN];
+    f32x4 xq[PF2 ? SI : 1][PF2 ? CBN : 1];   // PF2: the row of step+1 waits here while the row of step+2 is in flight
 #pragma unroll
     for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
-        for (int cb = 0; cb < CBN; ++cb) xr[iw][cb] = in4[((size_t)(e.x + iw) * (CIN / 4) + 4 * cb) * 32];
+        for (int cb = 0; cb < CBN; ++cb) {
+            xr[iw][cb] = in4[((size_t)(e.x + iw) * (CIN / 4) + 4 * cb) * 32];
+            if (PF2) xq[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];
+        }
     if (RESIDENT) {   // all taps of the layer stay in LDS (A.n_taps x WTAP float4): no per-step barrier
         for (int i = threadIdx.x; i < A.n_taps * WTAPL; i += 512) {
             const int t = i >> 6;
@@ -939,7 +943,14 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
                     }
                 }
 #pragma unroll
-                for (int cb = 0; cb < CBN; ++cb) xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
+                for (int cb = 0; cb < CBN; ++cb) {
+                    if (PF2) {
+                        xr[iw][cb] = xq[iw][cb];
+                        xq[iw][cb] = in4[((size_t)(en2.x + iw) * (CIN / 4) + 4 * cb) * 32];   // the row after next (index clamped)
+                    } else {
+                        xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
+                    }
+                }
             }
             last = (e.w & 2) != 0;
             e = en;

@@ -685,11 +685,11 @@ constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8,
 constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true>;
 constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (position-split launches)
 constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
-constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true>;    // weights LDS-resident
+constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, true>;    // weights LDS-resident
 constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true>;
-constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true>;
+constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, true>;
 constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 0, false, true>;
-constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true>;
+constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, true>;
 constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, false, true>;
 constexpr size_t LDS_ENC_DOWN_R = (size_t)64 * (1 * 2 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, resident
