@@ -814,8 +814,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false>
-__global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
     static_assert(INMODE == 0 || INMODE == 1, "raw or GroupNorm(8)+ReLU input");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int half = blockIdx.x * 8 + wave;
+    int half = blockIdx.x * NWV + wave;   // NWV half tiles per workgroup (16 for LDS-resident weights: 4 waves/SIMD behind one copy)
     const bool active = (half >> 1) < A.n_tiles;
     // waves past the last half tile only help staging the weights; in the launches without fused statistics (small batches: a
     // workgroup may hold 1 live wave and 7 idle ones) they also stay off the MFMA pipe their live neighbours need
@@ -877,13 +877,13 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
             if (PF2) xq[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];
         }
     if (RESIDENT) {   // all taps of the layer stay in LDS (A.n_taps x WTAP float4): no per-step barrier
-        for (int i = threadIdx.x; i < A.n_taps * WTAPL; i += 512) {
+        for (int i = threadIdx.x; i < A.n_taps * WTAPL; i += NWV * 64) {
             const int t = i >> 6;
             lds[i] = MSPLIT == 1 ? wg4[i] : wg4[(size_t)((t / MTL) * MTN + mz + t % MTL) * 64 + (i & 63)];
         }
         __syncthreads();
     } else {
-        for (int t = wave; t < WSTEPL / 64; t += 8) {
+        for (int t = wave; t < WSTEPL / 64; t += NWV) {
             const int piece = (t / MTL) * MTN + mz + t % MTL;
             glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEPL + t * 64);
         }
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(512, 1) void conv_rows16_k(ConvArgs A, const int4* 
                 __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight pieces and input row have landed
                 __syncthreads();                      // every wave's pieces of W(step) landed; every wave done reading W(step-1)
                 f32x4* dst = lds + ((si + 1) & 1) * WSTEPL;
-                for (int t = wave; t < WSTEPL / 64; t += 8) {
+                for (int t = wave; t < WSTEPL / 64; t += NWV) {
                     const int piece = (t / MTL) * MTN + mz + t % MTL;
                     glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + t * 64);
                 }

@@ -685,11 +685,11 @@ constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8,
 constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true>;
 constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (position-split launches)
 constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
-constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, true>;    // weights LDS-resident
+constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, true>;      // 8 waves, two-step prefetch    // weights LDS-resident
 constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true>;
-constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, true>;
+constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 16>;   // 16 waves behind one LDS copy (4/SIMD)
 constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 0, false, true>;
-constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, true>;
+constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, false, 16>;
 constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, false, true>;
 constexpr size_t LDS_ENC_DOWN_R = (size_t)64 * (1 * 2 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, resident
@@ -884,7 +884,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
-        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         ConvArgs A{};
@@ -892,7 +892,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
         A.out_csum = a["csum"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
-        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
+        L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     if (d_latent) {
         launch_latent_assign(c, L, n, d_idx, d_latent, s, 1);
