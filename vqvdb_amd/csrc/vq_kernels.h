@@ -1157,74 +1157,73 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
                                                   const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles,
                                                   const int* __restrict__ grp_start)
 {
-    __shared__ uint8_t sidx[4][64 * 32];
+    // The kernel is a gather from the 1.8 MB table (L2-resident), bound by the L1's tag rate: a wave covers 8 leaves x one
+    // 32-channel half of the table row, lane = (leaf l, 16-byte chunk c) with c fastest, so that the 8 lanes of a leaf read one
+    // whole 128-byte line per load (one lane per leaf reading its 128 bytes as 8 loads cost 8 tag lookups per line: 1.2 ms
+    // per 65536 leaves).  8 waves = one 32-leaf tile; three steps of table rows in flight per wave.
+    __shared__ uint8_t sidx[4][64 * 8];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
+    const int gw = blockIdx.x * 4 + wave;          // (tile, leaf octet o, half h) = gw / 8, (gw / 2) % 4, gw % 2
+    const int tile = gw >> 3, o = (gw >> 1) & 3, h = gw & 1;
     if (tile >= n_tiles) return;
-    const int j = lane & 31, h = lane >> 5;
-    const int64_t leaf = (int64_t)tile * 32 + j;
+    const int l = lane >> 3, c = lane & 7;
+    const int jt = 8 * o + l;                       // leaf within the tile
+    const int64_t leaf = (int64_t)tile * 32 + jt;
     uint8_t* my = sidx[wave];
-    for (int p = h; p < 64; p += 2) my[p * 32 + j] = leaf < n_leaves ? idx[leaf * 64 + p] : 0;
+    for (int p = c; p < 64; p += 8) my[p * 8 + l] = leaf < n_leaves ? idx[leaf * 64 + p] : 0;
     // (same wave writes and reads its own LDS region: program order suffices)
-    const f32x4* T4 = (const f32x4*)T + h * 8;
-    f32x4 b4[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) b4[g] = ((const f32x4*)bias)[h * 8 + g];
-    GnAcc st[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) st[g].init();
-    f32x4* out4 = (f32x4*)out + (size_t)tile * 64 * 16 * 32 + (size_t)h * 8 * 32 + j;
+    const f32x4* T4 = (const f32x4*)T + h * 8 + c;
+    const f32x4 b4 = ((const f32x4*)bias)[h * 8 + c];
+    GnAcc st;
+    st.init();
+    f32x4* out4 = (f32x4*)out + (size_t)tile * 64 * 16 * 32 + (size_t)(h * 8 + c) * 32 + jt;
 
     int g0, g1;
     split_range<64>(g0, g1);
     int si = gridDim.y > 1 ? grp_start[g0] : 0;
-    int4 e = steps[si];
-    int4 en = steps[si + 1];
-    f32x4 rn[8];
-    {
-        const int k = my[e.x * 32 + j];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) rn[g] = T4[((size_t)e.y * 256 + k) * 16 + g];
+    const int NSm = n_steps - 1;
+    int4 e = steps[si], e1 = steps[min(si + 1, NSm)], e2 = steps[min(si + 2, NSm)], e3 = steps[min(si + 3, NSm)];
+#define STEM_ROW(E) T4[((size_t)(E).y * 256 + my[(E).x * 8 + l]) * 16]
+    f32x4 r0 = STEM_ROW(e), r1 = STEM_ROW(e1), r2 = STEM_ROW(e2), r3;
+    int po = g0;
+    f32x4 acc = {0, 0, 0, 0};
+    bool done = false;
+#define STEM_STEP(RC, RN)                                                         \
+    if (!done) {                                                                  \
+        RN = STEM_ROW(e3); /* step si+3 into the register freed by the previous step */ \
+        const int4 e4 = steps[min(si + 4, NSm)];                                  \
+        acc = acc + RC;                                                           \
+        const bool last = (e.w & 2) != 0;                                         \
+        e = e1, e1 = e2, e2 = e3, e3 = e4;                                        \
+        ++si;                                                                     \
+        if (last) {                                                               \
+            const f32x4 v = acc + b4;                                             \
+            out4[(size_t)po * 16 * 32] = v;                                       \
+            st.add(v.x);                                                          \
+            st.add(v.y);                                                          \
+            st.add(v.z);                                                          \
+            st.add(v.w);                                                          \
+            acc = (f32x4){0, 0, 0, 0};                                            \
+            done = ++po == g1;                                                    \
+        }                                                                         \
     }
-    for (int po = g0; po < g1; ++po) {
-        f32x4 acc[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) acc[g] = (f32x4){0, 0, 0, 0};
-        bool last;
-        do {
-            f32x4 rc[8];
-#pragma unroll
-            for (int g = 0; g < 8; ++g) rc[g] = rn[g];
-            const int4 en2 = steps[si + 2 < n_steps ? si + 2 : n_steps - 1];
-            const int kn = my[en.x * 32 + j];
-#pragma unroll
-            for (int g = 0; g < 8; ++g) rn[g] = T4[((size_t)en.y * 256 + kn) * 16 + g];
-#pragma unroll
-            for (int g = 0; g < 8; ++g) acc[g] = acc[g] + rc[g];
-            last = (e.w & 2) != 0;
-            e = en;
-            en = en2;
-            ++si;
-        } while (!last);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const f32x4 v = acc[g] + b4[g];
-            out4[((size_t)po * 16 + g) * 32] = v;
-            st[g].add(v.x);
-            st[g].add(v.y);
-            st[g].add(v.z);
-            st[g].add(v.w);
-        }
+    while (!done) {
+        STEM_STEP(r0, r3)
+        STEM_STEP(r1, r0)
+        STEM_STEP(r2, r1)
+        STEM_STEP(r3, r2)
     }
+#undef STEM_STEP
+#undef STEM_ROW
     if (!out_mean) return;  // position-split launch: statistics by gn_stats_seq_k
-    // GroupNorm(8,64): group = 8 channels = two 4-channel partials (low + high), both owned by this lane
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    // GroupNorm(8,64): group = 8 channels = the 4-channel partials of lanes c (even, low) and c+1 (high): low + high
+    const double S = st.s + __shfl_xor(st.s, 1, 64), Q = st.q + __shfl_xor(st.q, 1, 64);
+    if ((c & 1) == 0) {
         float m, r;
-        gn_finish(st[2 * k].s + st[2 * k + 1].s, st[2 * k].q + st[2 * k + 1].q, 1.0 / 512.0, m, r);
-        out_mean[((size_t)tile * 8 + h * 4 + k) * 32 + j] = m;
-        out_rstd[((size_t)tile * 8 + h * 4 + k) * 32 + j] = r;
+        gn_finish(S, Q, 1.0 / 512.0, m, r);
+        out_mean[((size_t)tile * 8 + h * 4 + (c >> 1)) * 32 + jt] = m;
+        out_rstd[((size_t)tile * 8 + h * 4 + (c >> 1)) * 32 + jt] = r;
     }
 }
 

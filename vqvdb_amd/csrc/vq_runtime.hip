@@ -916,7 +916,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
     auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
     const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
     L.run("dec_stem_s", [&] {
-        hipLaunchKernelGGL(stem_lut_k, dim3(g4, split_factor(g4, 4, 16, 1024)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
+        hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt, split_factor(2 * nt, 2, 16, 2048)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
                            (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"));
     });
     L.run("dec_stats_ystem", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_ystem"], a["st_a.mean"], a["st_a.rstd"]); });
@@ -967,7 +967,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
 
     if (use_split(c, nt, true)) return decode_chunk_split(c, L, d_idx, n, d_out, s);
     L.run("dec_stem", [&] {
-        hipLaunchKernelGGL(stem_lut_k, dim3(g4), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
+        hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
                            (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
     });
     {
