@@ -338,6 +338,20 @@ def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
     a.close(), b.close()
 
 
+def test_small_batch_policy_setter(pack):
+    """vqhip_set_small_batch_tiles: -1 = automatic choice (default), 0 = never split, n = plain threshold; anything below -1 is
+    rejected loudly.  Whatever the policy, results do not change."""
+    c = HipCodec(pack)
+    x = synth.make_leaves(3000, seed=31)
+    ref = c.encode(x)
+    for tiles in (0, 1, 50, 1 << 20, -1):
+        c.set_small_batch_tiles(tiles)
+        assert np.array_equal(c.encode(x), ref), tiles
+    with pytest.raises(RuntimeError, match="small_batch_tiles"):
+        c.set_small_batch_tiles(-2)
+    c.close()
+
+
 def test_bench_two_rank_code_path_rehearsal():
     """bench.py's N > 1 path (rank-sharded seeds, barriers, max-over-ranks timing, all-reduce of the codebook statistics,
     one JSON line from rank 0) launched exactly like the driver does, with two ranks sharing the one GPU of this box
