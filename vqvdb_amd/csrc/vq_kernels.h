@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
     __shared__ float tile[32][65];
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int p0 = 0; p0 < 512; p0 += 64) {
+    // gridDim.y = 1: one workgroup walks the 8 position chunks of its tile; gridDim.y = 8 (small batches): one chunk each
+    const int pc0 = gridDim.y > 1 ? blockIdx.y * 64 : 0, pc1 = gridDim.y > 1 ? pc0 + 64 : 512;
+    for (int p0 = pc0; p0 < pc1; p0 += 64) {
         // read: 32 leaves x 64 positions, position fastest (256-B runs per leaf)
         for (int i = tid; i < 32 * 64; i += 256) {
             const int l = i >> 6, p = i & 63;

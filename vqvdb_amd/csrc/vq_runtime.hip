@@ -844,7 +844,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
-    L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt), dim3(256), 0, s, d_leaves, a["xt"], n); });
+    L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt, nt <= 128 ? 8 : 1), dim3(256), 0, s, d_leaves, a["xt"], n); });
     if (use_split(c, nt, false)) return encode_chunk_split(c, L, n, d_idx, s, d_latent);
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
