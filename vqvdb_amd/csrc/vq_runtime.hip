@@ -582,6 +582,7 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
 #undef UP
     if ((rc = upload_steps(c, "steps.k3s1_4", steps_conv(4, 4, 3, 1, 1, 1)))) return rc;     // one tap per step (streamed layers)
     if ((rc = upload_steps(c, "steps.rowgroups8_4", steps_rowgroups8(4)))) return rc;
+    if ((rc = upload_steps(c, "steps.rowgroups8_2", steps_rowgroups8(2)))) return rc;   // tiny batches: 32 groups of 2 rows
     if ((rc = upload_steps(c, "steps.rows_k3_4", steps_rows(4, 4, 3, 1, 1)))) return rc;
     if ((rc = upload_steps(c, "steps.rows_k4s2_8", steps_rows(8, 4, 4, 2, 1)))) return rc;
     if ((rc = upload_steps(c, "steps.rows8kd", steps_rows8_kd()))) return rc;
@@ -785,12 +786,22 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         ConvArgs A{};
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.grp_start = od("steps.rowgroups8_4");
-        L.run("enc_res16_conv1_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, false>), dim3((2 * nt + 3) / 4, split_factor((2 * nt + 3) / 4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        // a handful of tiles: two-row groups (32 ranges, half the serial chain per wave; same taps in the same order per output)
+        const int gq = (2 * nt + 3) / 4;
+        const bool two = gq * 32 <= 512;   // up to 1024 leaves (measured)
+        const char* tab = two ? "steps.rowgroups8_2" : "steps.rowgroups8_4";
+        A.n_steps = c->nsteps[tab], A.grp_start = od(tab);
+        L.run("enc_res16_conv1_s", [&] {
+            if (two) hipLaunchKernelGGL((conv8_c16_k<2, false, false>), dim3(gq, 32), dim3(256), 0, s, A, (const int4*)w[tab]);
+            else hipLaunchKernelGGL((conv8_c16_k<4, false, false>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w[tab]);
+        });
         L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 2>), dim3(nt), dim3(128), 0, s, a["e_y4"], a["st_a.mean"], a["st_a.rstd"]); });
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
-        L.run("enc_res16_conv2_s", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4, split_factor((2 * nt + 3) / 4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        L.run("enc_res16_conv2_s", [&] {
+            if (two) hipLaunchKernelGGL((conv8_c16_k<2, true, false>), dim3(gq, 32), dim3(256), 0, s, A, (const int4*)w[tab]);
+            else hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w[tab]);
+        });
     }
     {
         ConvArgs A{};
