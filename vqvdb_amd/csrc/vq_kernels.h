@@ -24,6 +24,7 @@ struct ConvArgs {
     const float* se_csum;    // [tile][CIN][32] channel sums over the 64 positions
     const float* se_fc0;     // [CIN/4][CIN]
     const float* se_fc2;     // [CIN][CIN/4]
+    const float* se_gate;    // tail_small_k: gates precomputed per tile by csum_seq_k, [tile][CIN][32]
     float* out_mean;         // [tile][GOUT][32]
     float* out_rstd;
     float* out_csum;         // [tile][COUT][32]
@@ -742,16 +743,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int tile = blockIdx.x, d = blockIdx.y;
     const int p0 = (d > 2 ? d - 2 : 0) * 16, p1 = ((d + 2 < 3 ? d + 2 : 3) + 1) * 16;   // an even number of positions (48 or 64)
     const int sbase = d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176;                      // first step of slab d in tail.w
-    float ta[NU][4];
-    {
-        float hid[CIN / 4], gall[CIN];
-        se_hidden<CIN>(A.se_csum + (size_t)tile * CIN * 32 + j, A.se_fc0, hid);
-        se_gates<CIN>(hid, A.se_fc2, gall);
+    float ta[NU][4];   // attention gates of this lane's channels 8u + 4q + i (precomputed once per tile by csum_seq_k)
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ta[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
-    }
+        for (int i = 0; i < 4; ++i) ta[u][i] = A.se_gate[((size_t)tile * CIN + 8 * u + 4 * q + i) * 32 + j];
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;       // + p*(CIN/4)*32 + u*64
     const f32x4* w4 = (const f32x4*)A.wfrag + ((size_t)(sbase - p0) * NU * NMT + mb) * 64 + lane;   // + (p*NU*NMT + u*NMT)*64
     f32x4 w[2][NU], b[2][NU];
@@ -1032,6 +1028,7 @@ struct VqArgs {
     const float* se_csum;   // [tile][32][32]
     const float* se_fc0;    // [8][32]
     const float* se_fc2;    // [32][8]
+    const float* se_gate;   // optional: gates precomputed per tile (position-split launches), [tile][32][32]
     const float* epfrag;    // A fragments of Ep: [u=4][ct=8][64][4]
     const float* ck_frag;   // D-fragment order [(ct*2+q)*16 + r]
     uint8_t* idx;           // [n_leaves][64]
@@ -1053,7 +1050,12 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
     if (tile >= A.n_tiles) return;
     const int j = lane & 31, q = lane >> 5;
     float gate[4][4];
-    {
+    if (A.se_gate) {   // (uniform) split launches: every position range would repeat the same prologue
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate[u][i] = A.se_gate[((size_t)tile * 32 + 8 * u + 4 * q + i) * 32 + j];
+    } else {
         float hid[8], gall[32];
         se_hidden<32>(A.se_csum + (size_t)tile * 32 * 32 + j, A.se_fc0, hid);
         se_gates<32>(hid, A.se_fc2, gall);
@@ -1293,7 +1295,8 @@ __global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __rest
 }
 
 template <int C, int NP>
-__global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict__ x, float* __restrict__ csum)
+__global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict__ x, float* __restrict__ csum, const float* __restrict__ fc0 = nullptr,
+                                                         const float* __restrict__ fc2 = nullptr, float* __restrict__ gates = nullptr)
 {
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
@@ -1306,6 +1309,26 @@ __global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict
     csum[((size_t)tile * C + 4 * quad + 1) * 32 + j] = s.y;
     csum[((size_t)tile * C + 4 * quad + 2) * 32 + j] = s.z;
     csum[((size_t)tile * C + 4 * quad + 3) * 32 + j] = s.w;
+    if (!gates) return;   // (uniform)
+    // ChannelAttention gates of the tile, once, with the C/4 hidden units and the C gates of a leaf spread over the workgroup's
+    // C/4 (quad) threads of that leaf: the same fmaf chains as se_hidden / se_gates (vq_device.h), which every consumer wave would
+    // otherwise run serially in its prologue (2 x C x C/4 fmafs behind C dependent loads).
+    constexpr int R = C / 4;
+    __shared__ float cs[C][32], hs[R][32];
+    cs[4 * quad + 0][j] = s.x, cs[4 * quad + 1][j] = s.y, cs[4 * quad + 2][j] = s.z, cs[4 * quad + 3][j] = s.w;
+    __syncthreads();
+    float h = 0.0f;
+    for (int c = 0; c < C; ++c) h = __builtin_fmaf(fc0[quad * C + c], cs[c][j] * (1.0f / 64.0f), h);
+    hs[quad][j] = h > 0.0f ? h : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * quad + i;
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) a = __builtin_fmaf(fc2[c * R + k], hs[k][j], a);
+        gates[((size_t)tile * C + c) * 32 + j] = vq_sigmoid(a);
+    }
 }
 
 template <int C, int NP, int G>

@@ -607,7 +607,7 @@ const ActSpec kActs[] = {
     {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
     {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},
     {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},
-    {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64},
+    {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64}, {"gate", 0, 64},
 };
 
 int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
@@ -832,7 +832,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
             if (ms) hipLaunchKernelGGL(k_enc_r32c2_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_enc_r32c2_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"]); });
+        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"], w["efc0"], w["efc2"], a["gate"]); });
     }
     if (d_latent) {
         launch_latent_assign(c, L, n, d_idx, d_latent, s, split_factor(g2, 8, 32, 512));
@@ -841,6 +841,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     VqArgs A{};
     A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
     A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
+    A.se_gate = a["gate"];   // computed once per tile by enc_csum_x11
     L.run("enc_vq_s", [&] { hipLaunchKernelGGL(vq_folded_k<2>, dim3(g2, split_factor(g2, 8, 32, 2048)), dim3(128), 0, s, A); });
     return L.rc;
 }
@@ -954,13 +955,14 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
             if (ms) hipLaunchKernelGGL(k_dec_r64c2_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_dec_r64c2_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"]); });
+        L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"], w["dfc0"], w["dfc2"], a["gate"]); });
     }
     {
         ConvArgs A{};
         A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
+        A.se_gate = a["gate"];   // computed once per tile by dec_csum_x6
         L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small_k, dim3(nt, 4), dim3(256), 0, s, A); });
     }
     return L.rc;
