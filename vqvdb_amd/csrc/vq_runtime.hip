@@ -752,13 +752,14 @@ int split_factor(int wgs, int lo, int n_groups, int target)
 }
 
 // Which path a pass of nt 32-leaf tiles takes.  One wave per tile fills the chip in rounds of 1024 tiles (1024 SIMDs), so its
-// time is a staircase (encode: 6.4 ms at 1024 tiles, 10.0 ms at 1056); the split path is linear (about 6.8 us per tile) and
-// wins below the first step and again just above it.  Crossovers measured with tools/small_batch_probe.py.
+// time is a staircase (encode: 7.6 ms at 1024 tiles, 10.0 ms at 1100); the split path is linear (about 6.8 us per tile for
+// encode, 6.1 us for decode) and wins up to about three quarters of a full 2048-tile chunk.  Crossovers measured with
+// tools/small_batch_probe.py.
 bool use_split(const vqhip_codec* c, int nt, bool decode)
 {
     if (c->split_tiles >= 0) return nt <= (decode ? 5 * c->split_tiles / 4 : c->split_tiles);
     if (decode) return nt <= 1700;
-    return nt <= 832 || (nt > 1024 && nt <= 1450);
+    return nt <= 1500;
 }
 
 // Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
