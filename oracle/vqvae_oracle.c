@@ -381,17 +381,26 @@ static void gn_stats(const float* x, int C, int G, int NP, float* mean /*[G][LT]
         double S[LT], Q[LT];
         for (int l = 0; l < LT; ++l) S[l] = Q[l] = 0.0;
         for (int part = 0; part < nparts; ++part) {
+            /* contract: the NP positions form 16 equal blocks; each block is one sequential chain (positions
+               ascending, channels ascending) starting from zero, and the block sums are added in block order.  A launch that
+               splits a layer over up to 16 position ranges can therefore fuse the statistics (per-block partials). */
             double s[LT], q[LT];
             for (int l = 0; l < LT; ++l) s[l] = q[l] = 0.0;
-            for (int p = 0; p < NP; ++p)
-                for (int cc = 0; cc < cpp; ++cc) {
-                    const float* v = x + ((size_t)(g * cpg + part * cpp + cc) * NP + p) * LT;
-                    for (int l = 0; l < LT; ++l) {
-                        const double d = (double)v[l];
-                        s[l] += d;
-                        q[l] = fma(d, d, q[l]);
+            const int BP = NP / 16;
+            for (int b = 0; b < 16; ++b) {
+                double sb[LT], qb[LT];
+                for (int l = 0; l < LT; ++l) sb[l] = qb[l] = 0.0;
+                for (int p = b * BP; p < (b + 1) * BP; ++p)
+                    for (int cc = 0; cc < cpp; ++cc) {
+                        const float* v = x + ((size_t)(g * cpg + part * cpp + cc) * NP + p) * LT;
+                        for (int l = 0; l < LT; ++l) {
+                            const double d = (double)v[l];
+                            sb[l] += d;
+                            qb[l] = fma(d, d, qb[l]);
+                        }
                     }
-                }
+                for (int l = 0; l < LT; ++l) { s[l] += sb[l]; q[l] += qb[l]; }
+            }
             if (part == 0) for (int l = 0; l < LT; ++l) { S[l] = s[l]; Q[l] = q[l]; }
             else for (int l = 0; l < LT; ++l) { S[l] = S[l] + s[l]; Q[l] = Q[l] + q[l]; }
         }
@@ -459,10 +468,15 @@ static void channel_attention(const float* x, float* out, int C, const float* fc
     const int R = C / 4, NP = 64;
     float m[64][LT], h[16][LT];
     for (int c = 0; c < C; ++c) {
-        float s[LT];
+        float s[LT];   /* same 16-block rule as gn_stats, in fp32 */
         for (int l = 0; l < LT; ++l) s[l] = 0.0f;
-        for (int p = 0; p < NP; ++p)
-            for (int l = 0; l < LT; ++l) s[l] = s[l] + x[((size_t)c * NP + p) * LT + l];
+        for (int b = 0; b < 16; ++b) {
+            float sb[LT];
+            for (int l = 0; l < LT; ++l) sb[l] = 0.0f;
+            for (int p = b * (NP / 16); p < (b + 1) * (NP / 16); ++p)
+                for (int l = 0; l < LT; ++l) sb[l] = sb[l] + x[((size_t)c * NP + p) * LT + l];
+            for (int l = 0; l < LT; ++l) s[l] = s[l] + sb[l];
+        }
         for (int l = 0; l < LT; ++l) m[c][l] = s[l] * (1.0f / 64.0f);
     }
     for (int j = 0; j < R; ++j)

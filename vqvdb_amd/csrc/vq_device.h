@@ -56,14 +56,24 @@ __device__ __forceinline__ float vq_expf(float x)
 __device__ __forceinline__ float vq_sigmoid(float x) { return 1.0f / (1.0f + vq_expf(-x)); }
 
 // GroupNorm statistics accumulator (fp64; same order as the oracle's gn_stats).
+// GroupNorm statistics under the 16-block contract (oracle gn_stats): the positions of a leaf form 16 equal blocks;
+// inside a block one sequential fp64 chain (positions ascending, channels ascending) starting from zero, block sums added in
+// block order.  add() feeds the open block, fold() closes it; s / q are the totals over the closed blocks.
 struct GnAcc {
-    double s, q;
-    __device__ __forceinline__ void init() { s = 0.0; q = 0.0; }
+    double s, q, bs, bq;
+    __device__ __forceinline__ void init() { s = 0.0; q = 0.0; bs = 0.0; bq = 0.0; }
     __device__ __forceinline__ void add(float v)
     {
         const double d = (double)v;
-        s += d;
-        q = fma(d, d, q);
+        bs += d;
+        bq = fma(d, d, bq);
+    }
+    __device__ __forceinline__ void fold()
+    {
+        s += bs;
+        q += bq;
+        bs = 0.0;
+        bq = 0.0;
     }
 };
 // mean / rstd from total sums over n = 2^k elements (fp64, rounded to fp32 at the end)

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
 //   MODE 1: recompute y1, a1 = relu(gn(y1)) -> store, statistics of a1 for GroupNorm(8,16).
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __restrict__ steps)
+__global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* __restrict__ steps)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -231,6 +231,12 @@ __global__ __launch_bounds__(256) void conv_first_k(ConvArgs A, const int4* __re
                     st[sb][1].add(v.w);
                 }
             }
+        if (MODE != 2 && (row & 3) == 3) {   // 4 rows = 32 positions = one statistics block
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int k = 0; k < (MODE == 1 ? 2 : 1); ++k) st[sb][k].fold();
+        }
     }
     if (MODE == 2) return;
 #pragma unroll
@@ -287,6 +293,10 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * NP * NG * 32 + (size_t)h * NGL * 32 + j;
 #pragma unroll 2
     for (int p = 0; p < NP; ++p) {
+        if (p > 0 && p % (NP / 16) == 0) {   // statistics block boundary
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) st[k].fold();
+        }
 #pragma unroll
         for (int gl = 0; gl < NGL; ++gl) {
             f32x4 v = in4[((size_t)p * NG + gl) * 32];
@@ -309,6 +319,8 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) st[k].fold();
     const double inv_n = 1.0 / (double)(CPGO * NP);
     if (CPGO == 2) {
 #pragma unroll
@@ -459,6 +471,11 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                 }
             }
         }
+        if (STATS) {   // NR rows closed: 16 statistics blocks of 32 positions per leaf
+            static_assert(!STATS || NR == 4, "statistics blocks are 4 rows");
+            st[0].fold();
+            st[1].fold();
+        }
     }
     if (STATS) {
 #pragma unroll
@@ -497,6 +514,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
+    static_assert(GOUT == 0 && !CSUM, "the fused statistics of this kernel predate the 16-block contract (no instantiation uses them)");
     constexpr int WTAP = NK * 64;            // float4 per tap
     constexpr int PIECES = WTAP / (NW * 64); // 1 KiB pieces per wave per streamed tap
     static_assert(!STREAM || (WTAP % (NW * 64) == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
@@ -851,9 +869,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     GnAcc st[GOUT > 0 ? MTN : 1];
 #pragma unroll
     for (int k = 0; k < (GOUT > 0 ? MTN : 1); ++k) st[k].init();
-    f32x4 cs[CSUM ? MTN : 1];
+    f32x4 cs[CSUM ? MTN : 1], csb[CSUM ? MTN : 1];   // channel sums: closed blocks / open block (same 16-block rule, fp32)
 #pragma unroll
-    for (int k = 0; k < (CSUM ? MTN : 1); ++k) cs[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < (CSUM ? MTN : 1); ++k) cs[k] = csb[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q4 * 32 + jj;   // + (pos*(CIN/4) + 4cb)*32
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj;
     const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj : nullptr;
@@ -978,8 +996,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                     st[mt].add(v.z);
                     st[mt].add(v.w);
                 }
-                if (CSUM) cs[mt] = cs[mt] + v;
+                if (CSUM) csb[mt] = csb[mt] + v;
             }
+        }
+        // one output row = 4 positions = one statistics block of a 4^3 layer
+        static_assert((GOUT == 0 && !CSUM) || NPO == 64, "statistics blocks are rows of 4 positions");
+        if (GOUT > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt) st[mt].fold();
+        }
+        if (CSUM) {
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt) cs[mt] = cs[mt] + csb[mt], csb[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
     if (!active) return;
@@ -1209,6 +1237,7 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
             st.add(v.z);                                                          \
             st.add(v.w);                                                          \
             acc = (f32x4){0, 0, 0, 0};                                            \
+            if ((po & 3) == 3) st.fold(); /* 4 positions = one statistics block */ \
             done = ++po == g1;                                                    \
         }                                                                         \
     }
@@ -1272,8 +1301,13 @@ __global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __rest
             st[0].add(u[k].y);
             st[CPG == 2 ? 1 : 0].add(u[k].z);
             st[CPG == 2 ? 1 : 0].add(u[k].w);
+            if ((k + 1) % (NP / 16 < NB ? NP / 16 : NB) == 0 && (NP / 16 <= NB)) {   // statistics block boundary (NP/16 = 4 or 32 positions)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) st[a].fold();
+            }
         }
     }
+    static_assert(NP / 16 <= 32 && 32 % (NP / 16) == 0, "blocks of NP/16 positions inside batches of 32");
     constexpr int G = C / CPG;
     if (CPG == 8) {  // group = this wave's two quads: low-quad partial + high-quad partial
         float m, r;
@@ -1303,8 +1337,13 @@ __global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict
     const int tile = blockIdx.x;
     const f32x4* in4 = (const f32x4*)x + (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
     f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-    for (int p = 0; p < NP; ++p) s = s + in4[(size_t)p * (C / 4) * 32];
+#pragma unroll(NP <= 64 ? 16 : 1)
+    for (int b = 0; b < 16; ++b) {   // 16-block rule: block sums from zero, added in block order
+        f32x4 sb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int p = b * (NP / 16); p < (b + 1) * (NP / 16); ++p) sb = sb + in4[(size_t)p * (C / 4) * 32];
+        s = s + sb;
+    }
     csum[((size_t)tile * C + 4 * quad + 0) * 32 + j] = s.x;
     csum[((size_t)tile * C + 4 * quad + 1) * 32 + j] = s.y;
     csum[((size_t)tile * C + 4 * quad + 2) * 32 + j] = s.z;
