@@ -75,7 +75,15 @@ struct GnAcc {
         bs = 0.0;
         bq = 0.0;
     }
+    // position-split launches: the block's sums also go to the partial buffers (gn_combine_k adds the 16 blocks in order)
+    __device__ __forceinline__ void fold_store(double* ps, double* pq, size_t i)
+    {
+        if (ps) ps[i] = bs, pq[i] = bq;
+        fold();
+    }
 };
+// index of (tile, statistics block, accumulator slot, leaf) in the partial buffers: 16 blocks x 16 slots x 32 leaves per tile
+__device__ __forceinline__ size_t part_index(int tile, int blk, int slot, int leaf) { return (((size_t)tile * 16 + blk) * 16 + slot) * 32 + leaf; }
 // mean / rstd from total sums over n = 2^k elements (fp64, rounded to fp32 at the end)
 __device__ __forceinline__ void gn_finish(double S, double Q, double inv_n, float& mean, float& rstd)
 {

@@ -34,9 +34,13 @@ struct ConvArgs {
     int n_tiles;
     // Position-split launches (small batches: too few leaf tiles to fill 1024 SIMDs): gridDim.y > 1 cuts the kernel's
     // output groups (the units its outer loop walks: rows, row groups or positions) into gridDim.y ranges;
-    // grp_start[g] = index of the first schedule step of group g.  Kernels launched this way are instantiated without
-    // fused statistics (gn_stats_seq_k / csum_seq_k recompute them in the contract's sequential order from the stored output).
+    // grp_start[g] = index of the first schedule step of group g.
     const int* grp_start;
+    // ... with fused statistics: a split launch covers whole statistics blocks (16 per leaf) and stores each block's sums
+    // here instead of finishing; gn_combine_k / csum_combine_k add the blocks in order (same result as the one-wave-per-tile launch)
+    double* part_s;          // [tile][16 blocks][16 slots][32]
+    double* part_q;
+    float* part_c;           // channel sums: [tile][16 blocks][64 channels][32]
 };
 
 // group range [g0, g1) of this workgroup for a kernel whose outer loop walks NG output groups
@@ -211,8 +215,12 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 f32x4 v = acc[ow][sb] + bias4;
-                if (MODE == 2) {  // plain conv output (position-split path)
+                if (MODE == 2) {  // plain conv output + statistics partials (position-split path)
                     out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;
+                    st[sb][0].add(v.x);
+                    st[sb][0].add(v.y);
+                    st[sb][0].add(v.z);
+                    st[sb][0].add(v.w);
                 } else if (MODE == 0) {
                     if (out4) out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;   // debug only
                     st[sb][0].add(v.x);
@@ -231,14 +239,15 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     st[sb][1].add(v.w);
                 }
             }
-        if (MODE != 2 && (row & 3) == 3) {   // 4 rows = 32 positions = one statistics block
+        if ((row & 3) == 3) {   // 4 rows = 32 positions = one statistics block; slot = GroupNorm group (4 of 4 channels / 8 of 2)
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int k = 0; k < (MODE == 1 ? 2 : 1); ++k) st[sb][k].fold();
+                for (int k = 0; k < (MODE == 1 ? 2 : 1); ++k)
+                    st[sb][k].fold_store(A.part_s, A.part_q, part_index(tile, row >> 2, MODE == 1 ? 2 * q4 + k : q4, 16 * sb + jj));
         }
     }
-    if (MODE == 2) return;
+    if (MODE == 2 || A.part_s) return;   // split launch: gn_combine_k finishes
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
         if (MODE == 0) {
@@ -291,12 +300,18 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
     for (int k = 0; k < NACC; ++k) st[k].init();
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NP * NG * 32 + (size_t)h * NGL * 32 + j;
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * NP * NG * 32 + (size_t)h * NGL * 32 + j;
-#pragma unroll 2
-    for (int p = 0; p < NP; ++p) {
-        if (p > 0 && p % (NP / 16) == 0) {   // statistics block boundary
+    int b0, b1;   // statistics blocks of this workgroup (all 16 unless the launch is position-split)
+    split_range<16>(b0, b1);
+    auto close_block = [&](int blk) {
 #pragma unroll
-            for (int k = 0; k < NACC; ++k) st[k].fold();
+        for (int k = 0; k < NACC; ++k) {
+            const int slot = CPGO == 2 ? h * NGL * 2 + k : h * NGL + k;   // group of 2 channels, or 4-channel partial of a group of 8
+            st[k].fold_store(A.part_s, A.part_q, part_index(tile, blk, slot, j));
         }
+    };
+#pragma unroll 2
+    for (int p = b0 * (NP / 16); p < b1 * (NP / 16); ++p) {
+        if (p > b0 * (NP / 16) && p % (NP / 16) == 0) close_block(p / (NP / 16) - 1);   // statistics block boundary
 #pragma unroll
         for (int gl = 0; gl < NGL; ++gl) {
             f32x4 v = in4[((size_t)p * NG + gl) * 32];
@@ -319,8 +334,8 @@ __global__ __launch_bounds__(256) void gn_relu_stats_k(ConvArgs A)
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) st[k].fold();
+    close_block(b1 - 1);
+    if (A.part_s) return;   // split launch: gn_combine_k finishes
     const double inv_n = 1.0 / (double)(CPGO * NP);
     if (CPGO == 2) {
 #pragma unroll
@@ -473,11 +488,11 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
         }
         if (STATS) {   // NR rows closed: 16 statistics blocks of 32 positions per leaf
             static_assert(!STATS || NR == 4, "statistics blocks are 4 rows");
-            st[0].fold();
-            st[1].fold();
+            st[0].fold_store(A.part_s, A.part_q, part_index(tile, grp, 2 * q4 + 0, jj));   // slot = GroupNorm(8,16) group
+            st[1].fold_store(A.part_s, A.part_q, part_index(tile, grp, 2 * q4 + 1, jj));
         }
     }
-    if (STATS) {
+    if (STATS && !A.part_s) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float m, r;
@@ -830,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8>
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -840,7 +855,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     // MSPLIT > 1 (small batches): blockIdx.z selects MTL of the MTN 16-cout blocks, so a wave's serial MFMA chain is MSPLIT times
     // shorter; the K order of every output is unchanged.  Only the needed weight pieces are staged, packed densely in LDS.
     constexpr int MTL = MTN / MSPLIT, WTAPL = WTAP / MSPLIT, WSTEPL = WSTEP / MSPLIT;
-    static_assert(MTN % MSPLIT == 0 && (MSPLIT == 1 || (GOUT == 0 && !CSUM)), "cout split: no fused statistics");
+    static_assert(MTN % MSPLIT == 0 && (MSPLIT == 1 || PARTS || (GOUT == 0 && !CSUM)), "cout split: statistics only as per-block partials");
     const int mz = MSPLIT > 1 ? blockIdx.z * MTL : 0;
     static_assert(INMODE == 0 || INMODE == 1, "raw or GroupNorm(8)+ReLU input");
     const int lane = threadIdx.x & 63;
@@ -849,7 +864,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     const bool active = (half >> 1) < A.n_tiles;
     // waves past the last half tile only help staging the weights; in the launches without fused statistics (small batches: a
     // workgroup may hold 1 live wave and 7 idle ones) they also stay off the MFMA pipe their live neighbours need
-    const bool work = (GOUT > 0 || CSUM) ? true : active;
+    // PARTS (position-split launches with fused statistics): per-block partial sums go to ConvArgs::part_* instead of being finished
+    static_assert(!PARTS || GOUT > 0 || CSUM, "PARTS: an instantiation with fused statistics");
+    const bool work = (!PARTS && (GOUT > 0 || CSUM)) ? true : active;
     if (!active) half = 2 * A.n_tiles - 1;
     const int tile = half >> 1;
     const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
@@ -1001,16 +1018,26 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
         }
         // one output row = 4 positions = one statistics block of a 4^3 layer
         static_assert((GOUT == 0 && !CSUM) || NPO == 64, "statistics blocks are rows of 4 positions");
-        if (GOUT > 0) {
+        if (GOUT > 0) {   // slot = 4-channel quad of the output (group of 4 at COUT = 32, half of a group of 8 at COUT = 64)
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt) st[mt].fold();
+            for (int mt = 0; mt < MTL; ++mt) {
+                if (PARTS) st[mt].fold_store(active ? A.part_s : nullptr, A.part_q, part_index(tile, row, 4 * (mz + mt) + q4, jj));
+                else st[mt].fold();
+            }
         }
         if (CSUM) {
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt) cs[mt] = cs[mt] + csb[mt], csb[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int mt = 0; mt < MTL; ++mt) {
+                if (PARTS && active) {
+                    const float v4[4] = {csb[mt].x, csb[mt].y, csb[mt].z, csb[mt].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A.part_c[(((size_t)tile * 16 + row) * 64 + 16 * (mz + mt) + 4 * q4 + r) * 32 + jj] = v4[r];
+                }
+                cs[mt] = cs[mt] + csb[mt], csb[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            }
         }
     }
-    if (!active) return;
+    if (!active || PARTS) return;   // PARTS: gn_combine_k / csum_combine_k finish
     if (GOUT > 0) {
         constexpr int CPGO = COUT / 8;
         static_assert(GOUT == 0 || (GOUT == 8 && (CPGO == 4 || CPGO == 8)), "GroupNorm(8, COUT) with COUT = 32 or 64");
@@ -1187,7 +1214,8 @@ __global__ __launch_bounds__(64) void build_stem_lut_k(const float* __restrict__
 __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ idx, const float* __restrict__ T, const float* __restrict__ bias,
                                                   float* __restrict__ out, float* __restrict__ out_mean, float* __restrict__ out_rstd,
                                                   const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles,
-                                                  const int* __restrict__ grp_start)
+                                                  const int* __restrict__ grp_start, double* __restrict__ part_s = nullptr,
+                                                  double* __restrict__ part_q = nullptr)
 {
     // The kernel is a gather from the 1.8 MB table (L2-resident), bound by the L1's tag rate: a wave covers 8 leaves x one
     // 32-channel half of the table row, lane = (leaf l, 16-byte chunk c) with c fastest, so that the 8 lanes of a leaf read one
@@ -1237,7 +1265,7 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
             st.add(v.z);                                                          \
             st.add(v.w);                                                          \
             acc = (f32x4){0, 0, 0, 0};                                            \
-            if ((po & 3) == 3) st.fold(); /* 4 positions = one statistics block */ \
+            if ((po & 3) == 3) st.fold_store(part_s, part_q, part_index(tile, po >> 2, h * 8 + c, jt)); /* 4 positions = one block */ \
             done = ++po == g1;                                                    \
         }                                                                         \
     }
@@ -1261,10 +1289,9 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
 }
 
 // ------------------------------------------------------------------------------------------
-// Sequential statistics for the position-split path.  The fused statistics of the conv kernels are one fp64 chain per
-// (leaf, group) over positions ascending, channels ascending; a split launch cannot continue that chain across
-// workgroups, so it stores the activations only and these kernels walk them again in exactly that order (a wave
-// streams its slice at L2 speed; the chain itself is ~10 us for 512 positions).
+// Stand-alone statistics of a stored activation, by the 16-block rule (same results as the fused ones).  The training step uses
+// them (its forward keeps every activation and recomputes the statistics the backward pass needs); the inference split path
+// fuses its statistics as per-block partials instead.
 //   gn_stats_seq_k<C, NP, CPG>: mean / rstd of GroupNorm with CPG (2, 4 or 8) channels per group, [tile][C/CPG][32]
 //   csum_seq_k<C, NP>         : per-channel fp32 sums over the positions (ChannelAttention), [tile][C][32]
 //   ew_gn_relu_k<C, G>        : y = relu(GroupNorm_G(x)) elementwise (first-conv output, VQVAE_v2.py:236-237)
@@ -1328,6 +1355,31 @@ __global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __rest
     }
 }
 
+// ChannelAttention gates of a tile, once, with the C/4 hidden units and the C gates of a leaf spread over the workgroup's C/4
+// (quad) threads of that leaf: the same fmaf chains as se_hidden / se_gates (vq_device.h), which every consumer wave would
+// otherwise run serially in its prologue (2 x C x C/4 fmafs behind C dependent loads).  s = this thread's 4 channel sums.
+template <int C>
+__device__ __forceinline__ void se_gates_block(int tile, int quad, int j, f32x4 s, const float* __restrict__ fc0, const float* __restrict__ fc2,
+                                               float* __restrict__ gates)
+{
+    constexpr int R = C / 4;
+    __shared__ float cs[C][32], hs[R][32];
+    cs[4 * quad + 0][j] = s.x, cs[4 * quad + 1][j] = s.y, cs[4 * quad + 2][j] = s.z, cs[4 * quad + 3][j] = s.w;
+    __syncthreads();
+    float h = 0.0f;
+    for (int c = 0; c < C; ++c) h = __builtin_fmaf(fc0[quad * C + c], cs[c][j] * (1.0f / 64.0f), h);
+    hs[quad][j] = h > 0.0f ? h : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * quad + i;
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) a = __builtin_fmaf(fc2[c * R + k], hs[k][j], a);
+        gates[((size_t)tile * C + c) * 32 + j] = vq_sigmoid(a);
+    }
+}
+
 template <int C, int NP>
 __global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict__ x, float* __restrict__ csum, const float* __restrict__ fc0 = nullptr,
                                                          const float* __restrict__ fc2 = nullptr, float* __restrict__ gates = nullptr)
@@ -1348,26 +1400,50 @@ __global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict
     csum[((size_t)tile * C + 4 * quad + 1) * 32 + j] = s.y;
     csum[((size_t)tile * C + 4 * quad + 2) * 32 + j] = s.z;
     csum[((size_t)tile * C + 4 * quad + 3) * 32 + j] = s.w;
-    if (!gates) return;   // (uniform)
-    // ChannelAttention gates of the tile, once, with the C/4 hidden units and the C gates of a leaf spread over the workgroup's
-    // C/4 (quad) threads of that leaf: the same fmaf chains as se_hidden / se_gates (vq_device.h), which every consumer wave would
-    // otherwise run serially in its prologue (2 x C x C/4 fmafs behind C dependent loads).
-    constexpr int R = C / 4;
-    __shared__ float cs[C][32], hs[R][32];
-    cs[4 * quad + 0][j] = s.x, cs[4 * quad + 1][j] = s.y, cs[4 * quad + 2][j] = s.z, cs[4 * quad + 3][j] = s.w;
-    __syncthreads();
-    float h = 0.0f;
-    for (int c = 0; c < C; ++c) h = __builtin_fmaf(fc0[quad * C + c], cs[c][j] * (1.0f / 64.0f), h);
-    hs[quad][j] = h > 0.0f ? h : 0.0f;
-    __syncthreads();
+    if (gates) se_gates_block<C>(tile, quad, j, s, fc0, fc2, gates);   // (uniform)
+}
+
+// Position-split launches with fused statistics: add the 16 block sums of every accumulator slot in block order (the fold()
+// chain of the one-wave-per-tile launch) and finish.  PAIR: groups of 8 channels = low quad + high quad (slots 2g, 2g+1).
+template <bool PAIR>
+__global__ __launch_bounds__(512) void gn_combine_k(const double* __restrict__ ps, const double* __restrict__ pq, float* __restrict__ mean,
+                                                    float* __restrict__ rstd, int n_groups, double inv_n)
+{
+    const int tile = blockIdx.x, slot = threadIdx.x >> 5, j = threadIdx.x & 31;
+    double S = 0.0, Q = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = 4 * quad + i;
-        float a = 0.0f;
-#pragma unroll
-        for (int k = 0; k < R; ++k) a = __builtin_fmaf(fc2[c * R + k], hs[k][j], a);
-        gates[((size_t)tile * C + c) * 32 + j] = vq_sigmoid(a);
+    for (int b = 0; b < 16; ++b) {
+        S += ps[part_index(tile, b, slot, j)];
+        Q += pq[part_index(tile, b, slot, j)];
     }
+    if (PAIR) {   // slots 2g (lanes 0..31 of the wave) and 2g+1 (lanes 32..63)
+        S = S + shfl_xor32_f64(S);
+        Q = Q + shfl_xor32_f64(Q);
+        if (slot & 1) return;
+    }
+    float m, r;
+    gn_finish(S, Q, inv_n, m, r);
+    const int g = PAIR ? slot >> 1 : slot;
+    mean[((size_t)tile * n_groups + g) * 32 + j] = m;
+    rstd[((size_t)tile * n_groups + g) * 32 + j] = r;
+}
+
+// ... and the channel sums (+ attention gates, like csum_seq_k)
+template <int C>
+__global__ __launch_bounds__(64 * C / 8) void csum_combine_k(const float* __restrict__ pc, float* __restrict__ csum, const float* __restrict__ fc0,
+                                                             const float* __restrict__ fc2, float* __restrict__ gates)
+{
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
+    const int tile = blockIdx.x;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] + pc[(((size_t)tile * 16 + b) * 64 + 4 * quad + r) * 32 + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[((size_t)tile * C + 4 * quad + r) * 32 + j] = v[r];
+    se_gates_block<C>(tile, quad, j, (f32x4){v[0], v[1], v[2], v[3]}, fc0, fc2, gates);
 }
 
 template <int C, int NP, int G>

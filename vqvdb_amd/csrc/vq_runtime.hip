@@ -608,6 +608,7 @@ const ActSpec kActs[] = {
     {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},
     {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},
     {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64}, {"gate", 0, 64},
+    {"part_s", 0, 512},   {"part_q", 0, 512},   {"part_c", 0, 1024},   // per-block statistics partials of split launches (fp64 x 256, fp32 x 1024)
 };
 
 int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
@@ -684,14 +685,17 @@ constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, fals
 //                                           CIN COUT SI SO KS ST PD INMODE RESID GOUT CSUM
 constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false>;   // row-blocked 16x16x4 convs (4^3 outputs)
 constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true>;
-constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (position-split launches)
+constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (training forward, data gradients)
 constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
+// position-split inference launches: fused statistics as per-block partials (PARTS)
+constexpr auto k_dec_r64c1_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, true>;
+constexpr auto k_dec_r64c2_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, true>;
 constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, true>;      // 8 waves, two-step prefetch    // weights LDS-resident
-constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true>;
+constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, true>;   // position-split launches (8-wave workgroups), per-block partials
 constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 16>;   // 16 waves behind one LDS copy (4/SIMD)
-constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 0, false, true>;
+constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 8, true>;
 constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, false, 16>;
-constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, false, true>;
+constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, false, 8, true>;
 constexpr size_t LDS_ENC_DOWN_R = (size_t)64 * (1 * 2 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, resident
 constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 KB weight window
@@ -699,11 +703,11 @@ constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 
 // position-split variants that additionally split the output channels over gridDim.z (a wave's serial MFMA chain is the latency
 // of a small batch): the 4^3 convs for the tiniest batches; the folded tail has its own small-batch kernel (tail_small_k)
-constexpr auto k_dec_r64c1_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false, false, 4>;
-constexpr auto k_dec_r64c2_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false, false, 4>;
-constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 0, false, true, 2>;
-constexpr auto k_enc_r32c1_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 0, false, true, 2>;
-constexpr auto k_enc_r32c2_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, false, true, 2>;
+constexpr auto k_dec_r64c1_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 4, false, 8, true>;
+constexpr auto k_dec_r64c2_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 4, false, 8, true>;
+constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 2, false, 8, true>;    // (statistics as per-block partials)
+constexpr auto k_enc_r32c1_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 2, false, 8, true>;
+constexpr auto k_enc_r32c2_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 2, false, 8, true>;
 // position-split (small-batch) variants: 2 tiles per workgroup, no fused statistics
 
 constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + projection A-fragments (144 KB)
@@ -721,6 +725,8 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_dec_r64c2_r, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c1_rs, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rs, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c1_rp, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c2_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
     return VQHIP_OK;
@@ -752,19 +758,19 @@ int split_factor(int wgs, int lo, int n_groups, int target)
 }
 
 // Which path a pass of nt 32-leaf tiles takes.  One wave per tile fills the chip in rounds of 1024 tiles (1024 SIMDs), so its
-// time is a staircase (encode: 7.6 ms at 1024 tiles, 10.0 ms at 1100); the split path is linear (about 6.8 us per tile for
-// encode, 6.1 us for decode) and wins up to about three quarters of a full 2048-tile chunk.  Crossovers measured with
+// time is a staircase (encode: 7.7 ms at 1024 tiles, 10.2 ms at 1536); the split path is linear (about 6.4 us per tile for
+// encode, 5.9 us for decode) and wins up to about 85 % of a full 2048-tile chunk.  Crossovers measured with
 // tools/small_batch_probe.py.
 bool use_split(const vqhip_codec* c, int nt, bool decode)
 {
     if (c->split_tiles >= 0) return nt <= (decode ? 5 * c->split_tiles / 4 : c->split_tiles);
-    if (decode) return nt <= 1700;
-    return nt <= 1500;
+    return nt <= (decode ? 1760 : 1728);
 }
 
 // Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
-// od-slabs split over gridDim.y workgroups, activations are stored, and the GroupNorm / channel-sum statistics are
-// recomputed by sequential kernels in the contract's order.  Same results bit for bit, ~5x lower latency.
+// groups split over gridDim.y (and, for the tiniest batches, its output channels over gridDim.z) workgroups.  Each workgroup
+// covers whole statistics blocks (16 per leaf, the contract's 16-block rule) and stores their partial sums; gn_combine_k /
+// csum_combine_k add the blocks in order.  Same results bit for bit, 15-25x lower latency.
 int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, hipStream_t s, float* d_latent)
 {
     const int nt = (int)((n + 31) / 32);
@@ -772,31 +778,39 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     auto& w = c->dw;
     auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
     const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2, gh = (2 * nt + 7) / 8;   // gh: workgroups of 8 half tiles (conv_rows16_k)
+    double* ps = reinterpret_cast<double*>(a["part_s"]);
+    double* pq = reinterpret_cast<double*>(a["part_q"]);
+    // Every launch covers whole statistics blocks (16 per leaf) and stores their sums; gn_combine_k adds them in block order.
+    auto combine = [&](const char* name, int groups, double inv_n, float* mean, float* rstd) {
+        L.run(name, [&] { hipLaunchKernelGGL(gn_combine_k<false>, dim3(nt), dim3(groups * 32), 0, s, ps, pq, mean, rstd, groups, inv_n); });
+    };
     {
         ConvArgs A{};
         A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd");
+        A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
-        L.run("enc_stats_y1", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 4>), dim3(nt), dim3(128), 0, s, a["e_y1"], a["st_a.mean"], a["st_a.rstd"]); });
-        L.run("enc_gn_relu_a1", [&] {
-            hipLaunchKernelGGL((ew_gn_relu_k<16, 512, 4>), dim3(nt, 16), dim3(256), 0, s, a["e_y1"], a["e_a1"], a["st_a.mean"], a["st_a.rstd"], w["eg0.w"], w["eg0.b"]);
-        });
-        L.run("enc_stats_a1", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 2>), dim3(nt), dim3(128), 0, s, a["e_a1"], a["st_b.mean"], a["st_b.rstd"]); });
+        combine("enc_stats_y1", 4, 1.0 / 2048.0, a["st_a.mean"], a["st_a.rstd"]);
+        ConvArgs B{};
+        B.in = a["e_y1"], B.out = a["e_a1"], B.in_mean = a["st_a.mean"], B.in_rstd = a["st_a.rstd"], B.in_gamma = w["eg0.w"], B.in_beta = w["eg0.b"];
+        B.n_tiles = nt, B.part_s = ps, B.part_q = pq;
+        L.run("enc_gn_relu_a1", [&] { hipLaunchKernelGGL((gn_relu_stats_k<16, 512, 4>), dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, B); });
+        combine("enc_stats_a1", 8, 1.0 / 1024.0, a["st_b.mean"], a["st_b.rstd"]);
     }
     {
         ConvArgs A{};
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
-        // a handful of tiles: two-row groups (32 ranges, half the serial chain per wave; same taps in the same order per output)
         const int gq = (2 * nt + 3) / 4;
+        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.grp_start = od("steps.rowgroups8_4"), A.part_s = ps, A.part_q = pq;
+        // conv1 carries the statistics: one range = one four-row group = one statistics block
+        L.run("enc_res16_conv1_s", [&] {
+            hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]);
+        });
+        combine("enc_stats_y4", 8, 1.0 / 1024.0, a["st_a.mean"], a["st_a.rstd"]);
+        // conv2 has none: a handful of tiles take two-row groups (32 ranges, half the serial chain per wave; same taps in the same order)
         const bool two = gq * 32 <= 512;   // up to 1024 leaves (measured)
         const char* tab = two ? "steps.rowgroups8_2" : "steps.rowgroups8_4";
-        A.n_steps = c->nsteps[tab], A.grp_start = od(tab);
-        L.run("enc_res16_conv1_s", [&] {
-            if (two) hipLaunchKernelGGL((conv8_c16_k<2, false, false>), dim3(gq, 32), dim3(256), 0, s, A, (const int4*)w[tab]);
-            else hipLaunchKernelGGL((conv8_c16_k<4, false, false>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w[tab]);
-        });
-        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<16, 512, 2>), dim3(nt), dim3(128), 0, s, a["e_y4"], a["st_a.mean"], a["st_a.rstd"]); });
+        A.n_steps = c->nsteps[tab], A.grp_start = od(tab), A.part_s = nullptr, A.part_q = nullptr;
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
         L.run("enc_res16_conv2_s", [&] {
@@ -807,33 +821,34 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     {
         ConvArgs A{};
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.grp_start = od("steps.rows_k4s2_8");
+        A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64, A.grp_start = od("steps.rows_k4s2_8"), A.part_s = ps, A.part_q = pq;
         const int psr = split_factor(gh, 4, 16, 512);
         L.run("enc_down_s", [&] {
             if (gh * psr * 2 <= 256) hipLaunchKernelGGL(k_enc_down_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_DOWN_R / 2, s, A, (const int4*)w["steps.rows_k4s2_8"]);
             else hipLaunchKernelGGL(k_enc_down_rs, dim3(gh, psr), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]);
         });
-        L.run("enc_stats_x7", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_x7"], a["st_b.mean"], a["st_b.rstd"]); });
+        combine("enc_stats_x7", 8, 1.0 / 256.0, a["st_b.mean"], a["st_b.rstd"]);
     }
     {
         ConvArgs A{};
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w16"], A.bias_frag = w["r32c1.braw"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
-        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
+        A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4"), A.part_s = ps, A.part_q = pq;
         const int psr = split_factor(gh, 4, 16, 512);
         const bool ms = gh * psr * 2 <= 256;   // up to 1024 leaves (measured): also split the 32 couts over gridDim.z
         L.run("enc_res32_conv1_s", [&] {
             if (ms) hipLaunchKernelGGL(k_enc_r32c1_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_enc_r32c1_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("enc_stats_y9", [&] { hipLaunchKernelGGL((gn_stats_seq_k<32, 64, 4>), dim3(nt), dim3(256), 0, s, a["e_y9"], a["st_a.mean"], a["st_a.rstd"]); });
+        combine("enc_stats_y9", 8, 1.0 / 256.0, a["st_a.mean"], a["st_a.rstd"]);
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w16"], A.bias_frag = w["r32c2.braw"], A.skip = a["e_x7"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
+        A.part_s = nullptr, A.part_q = nullptr, A.part_c = a["part_c"];
         L.run("enc_res32_conv2_s", [&] {
             if (ms) hipLaunchKernelGGL(k_enc_r32c2_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_enc_r32c2_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_seq_k<32, 64>), dim3(nt), dim3(256), 0, s, a["e_x11"], a["csum"], w["efc0"], w["efc2"], a["gate"]); });
+        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_combine_k<32>), dim3(nt), dim3(256), 0, s, a["part_c"], a["csum"], w["efc0"], w["efc2"], a["gate"]); });
     }
     if (d_latent) {
         launch_latent_assign(c, L, n, d_idx, d_latent, s, split_factor(g2, 8, 32, 512));
@@ -928,35 +943,46 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
     auto& w = c->dw;
     auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
     const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2;
+    double* ps = reinterpret_cast<double*>(a["part_s"]);
+    double* pq = reinterpret_cast<double*>(a["part_q"]);
+    // fused statistics of split launches: per-block partials + gn_combine_k (16 slots = the 4-channel halves of GroupNorm(8,64))
+    auto combine64 = [&](const char* name, float* mean, float* rstd) {
+        L.run(name, [&] { hipLaunchKernelGGL(gn_combine_k<true>, dim3(nt), dim3(512), 0, s, ps, pq, mean, rstd, 8, 1.0 / 512.0); });
+    };
     L.run("dec_stem_s", [&] {
         hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt, split_factor(2 * nt, 2, 16, 2048)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
-                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"));
+                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"), ps, pq);
     });
-    L.run("dec_stats_ystem", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_ystem"], a["st_a.mean"], a["st_a.rstd"]); });
-    L.run("dec_gn_relu_d2", [&] {
-        hipLaunchKernelGGL((ew_gn_relu_k<64, 64, 8>), dim3(nt, 8), dim3(256), 0, s, a["d_ystem"], a["d_d2"], a["st_a.mean"], a["st_a.rstd"], w["dg0.w"], w["dg0.b"]);
-    });
-    L.run("dec_stats_d2", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_d2"], a["st_b.mean"], a["st_b.rstd"]); });
+    combine64("dec_stats_ystem", a["st_a.mean"], a["st_a.rstd"]);
+    {
+        ConvArgs A{};
+        A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
+        A.in_gamma = w["dg0.w"], A.in_beta = w["dg0.b"], A.n_tiles = nt, A.part_s = ps, A.part_q = pq;
+        L.run("dec_gn_relu_d2", [&] { hipLaunchKernelGGL((gn_relu_stats_k<64, 64, 8>), dim3(g4, split_factor(g4, 2, 16, 1024)), dim3(256), 0, s, A); });
+    }
+    combine64("dec_stats_d2", a["st_b.mean"], a["st_b.rstd"]);
     {
         ConvArgs A{};
         A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r64g1.w"], A.in_beta = w["r64g1.b"], A.n_tiles = nt;
         A.wfrag = w["r64c1.w16"], A.bias_frag = w["r64c1.braw"];
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4");
+        A.part_s = ps, A.part_q = pq;
         const int gh = (2 * nt + 7) / 8, psr = split_factor(gh, 4, 16, 512);   // 8 half tiles per workgroup, 16 output rows to split
         const bool ms = gh * psr * 4 <= 1024;   // up to 2048 leaves (measured): also split the 64 couts over gridDim.z
         L.run("dec_res64_conv1_s", [&] {
             if (ms) hipLaunchKernelGGL(k_dec_r64c1_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
-            else hipLaunchKernelGGL(k_dec_r64c1_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else hipLaunchKernelGGL(k_dec_r64c1_rp, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("dec_stats_y4", [&] { hipLaunchKernelGGL((gn_stats_seq_k<64, 64, 8>), dim3(nt), dim3(512), 0, s, a["d_y4"], a["st_a.mean"], a["st_a.rstd"]); });
+        combine64("dec_stats_y4", a["st_a.mean"], a["st_a.rstd"]);
         A.in = a["d_y4"], A.out = a["d_x6"], A.wfrag = w["r64c2.w16"], A.bias_frag = w["r64c2.braw"], A.skip = a["d_d2"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
+        A.part_s = nullptr, A.part_q = nullptr, A.part_c = a["part_c"];
         L.run("dec_res64_conv2_s", [&] {
             if (ms) hipLaunchKernelGGL(k_dec_r64c2_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
-            else hipLaunchKernelGGL(k_dec_r64c2_rs, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else hipLaunchKernelGGL(k_dec_r64c2_rp, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_seq_k<64, 64>), dim3(nt), dim3(512), 0, s, a["d_x6"], a["csum"], w["dfc0"], w["dfc2"], a["gate"]); });
+        L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_combine_k<64>), dim3(nt), dim3(512), 0, s, a["part_c"], a["csum"], w["dfc0"], w["dfc2"], a["gate"]); });
     }
     {
         ConvArgs A{};
