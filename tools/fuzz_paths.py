@@ -13,10 +13,11 @@ from vqvdb_amd.codec import HipCodec
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 pack = weightpack.dumps(synth.make_weights(0))
-a, b = HipCodec(pack), HipCodec(pack)
-b.set_small_batch_tiles(0)
+a, b, f = HipCodec(pack), HipCodec(pack), HipCodec(pack)
+b.set_small_batch_tiles(0)          # one wave per tile everywhere
+f.set_small_batch_tiles(1 << 20)    # position-split launches everywhere, also for full 2048-tile chunks
 rng = np.random.default_rng(2024)
-pool = synth.make_leaves(60000, seed=77)
+pool = synth.make_leaves(70000, seed=77)
 # adversarial leaves mixed in: zeros, ones, spikes, huge, tiny
 pool[:8] = 0.0
 pool[8:16] = 1.0
@@ -26,13 +27,16 @@ pool[24:32] *= 1e-30
 t0, it, tot = time.time(), 0, 0
 while time.time() - t0 < budget:
     r = rng.random()
-    n = int(rng.integers(1, 200)) if r < 0.3 else int(rng.integers(1, 4000)) if r < 0.6 else int(rng.integers(1, 60001))
-    start = int(rng.integers(0, 60000 - n + 1))
+    n = int(rng.integers(1, 200)) if r < 0.3 else int(rng.integers(1, 4000)) if r < 0.6 else int(rng.integers(1, 70001))
+    start = int(rng.integers(0, 70000 - n + 1))
     x = pool[start:start + n]
     ia, ib = a.encode(x), b.encode(x)
     assert np.array_equal(ia, ib), (it, n, start, "indices")
     ra, rb = a.decode(ia), b.decode(ib)
     assert np.array_equal(ra.view(np.uint32), rb.view(np.uint32)), (it, n, start, "voxels")
+    if it % 4 == 0:
+        assert np.array_equal(f.encode(x), ib), (it, n, start, "indices, split everywhere")
+        assert np.array_equal(f.decode(ib).view(np.uint32), rb.view(np.uint32)), (it, n, start, "voxels, split everywhere")
     # random indices too (codes the encoder never emits next to each other)
     ri = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
     assert np.array_equal(a.decode(ri).view(np.uint32), b.decode(ri).view(np.uint32)), (it, n, "random indices")
