@@ -858,7 +858,11 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
     A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
     A.se_gate = a["gate"];   // computed once per tile by enc_csum_x11
-    L.run("enc_vq_s", [&] { hipLaunchKernelGGL(vq_folded_k<2>, dim3(g2, split_factor(g2, 8, 32, 2048)), dim3(128), 0, s, A); });
+    L.run("enc_vq_s", [&] {
+        // mid-size batches: 8 tiles behind one copy of the folded codebook in LDS (33 KB) instead of 2
+        if (nt >= 256) hipLaunchKernelGGL(vq_folded_k<8>, dim3((nt + 7) / 8, split_factor((nt + 7) / 8, 2, 32, 512)), dim3(512), 0, s, A);
+        else hipLaunchKernelGGL(vq_folded_k<2>, dim3(g2, split_factor(g2, 8, 32, 2048)), dim3(128), 0, s, A);
+    });
     return L.rc;
 }
 
