@@ -784,7 +784,19 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     auto combine = [&](const char* name, int groups, double inv_n, float* mean, float* rstd) {
         L.run(name, [&] { hipLaunchKernelGGL(gn_combine_k<false>, dim3(nt), dim3(groups * 32), 0, s, ps, pq, mean, rstd, groups, inv_n); });
     };
-    {
+    if (nt >= 256) {
+        // mid-size batches: the first conv twice (statistics, then recompute + normalise + store), like the one-wave-per-tile path,
+        // instead of storing its raw output and normalising it in an elementwise pass (2 x 32 KiB per leaf less traffic)
+        ConvArgs A{};
+        A.in = a["xt"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
+        const int psf = split_factor(g4, 8, 16, 1024);
+        L.run("enc_conv_first_stats_s", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        combine("enc_stats_y1", 4, 1.0 / 2048.0, a["st_a.mean"], a["st_a.rstd"]);
+        A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
+        L.run("enc_conv_first_gn_s", [&] { hipLaunchKernelGGL(conv_first_k<1>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        combine("enc_stats_a1", 8, 1.0 / 1024.0, a["st_b.mean"], a["st_b.rstd"]);
+    } else {
         ConvArgs A{};
         A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
