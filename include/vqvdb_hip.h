@@ -142,8 +142,8 @@ int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
 /* Small passes run the position-split kernels: each layer's output rows are spread over 4-16x more workgroups (the tiniest
  * batches also split the output channels) and the GroupNorm statistics are fused as per-block partial sums (16-block rule), which cuts the
  * latency of small batches (the SOP default of 64 leaves, training batches of 2048) 10-20x with bit-identical results.
- * Default (-1): automatic, from the measured crossovers — encode up to 1728 tiles (55296 leaves), decode up to 1760 tiles;
- * one wave per tile otherwise.  tiles >= 0 sets a plain threshold instead (encode `tiles`, decode 1.25x);
+ * Default (-1): automatic, from the measured crossovers — up to 1800 tiles (57600 leaves) in both directions; one wave per
+ * tile otherwise.  tiles >= 0 sets a plain threshold instead (encode `tiles`, decode 1.25x);
  * 0 disables the split path. */
 int vqhip_set_small_batch_tiles(vqhip_codec* codec, int tiles);
 

@@ -759,12 +759,12 @@ int split_factor(int wgs, int lo, int n_groups, int target)
 
 // Which path a pass of nt 32-leaf tiles takes.  One wave per tile fills the chip in rounds of 1024 tiles (1024 SIMDs), so its
 // time is a staircase (encode: 7.7 ms at 1024 tiles, 10.2 ms at 1536); the split path is linear (about 6.4 us per tile for
-// encode, 5.9 us for decode) and wins up to about 85 % of a full 2048-tile chunk.  Crossovers measured with
+// encode, 5.9 us for decode) and wins up to about 88 % of a full 2048-tile chunk.  Crossovers measured with
 // tools/small_batch_probe.py.
 bool use_split(const vqhip_codec* c, int nt, bool decode)
 {
     if (c->split_tiles >= 0) return nt <= (decode ? 5 * c->split_tiles / 4 : c->split_tiles);
-    return nt <= (decode ? 1760 : 1728);
+    return nt <= 1800;   // both directions (57600 leaves)
 }
 
 // Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
