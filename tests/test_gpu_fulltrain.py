@@ -217,10 +217,11 @@ def test_epoch_driver_full_mode(weights, tmp_path):
     c.close()
 
 
-def test_gradients_do_not_depend_on_the_launch_path(weights):
+@pytest.mark.parametrize("n", [96, 8192])
+def test_gradients_do_not_depend_on_the_launch_path(weights, n):
     """The training forward reuses the inference encoder kernels: one-wave-per-tile launches (large batches) and position-split
-    launches (small batches) must give the same gradients; so must a batch that straddles tiles differently."""
-    x = synth.make_leaves(96, seed=6100)
+    launches (small batches; from 256 tiles up with the first conv run twice) must give the same gradients."""
+    x = synth.make_leaves(n, seed=6100)
     a, b = HipCodec(weightpack.dumps(weights)), HipCodec(weightpack.dumps(weights))
     a.fulltrain_begin(), b.fulltrain_begin()
     b.set_small_batch_tiles(0)                       # b: classic encoder path (what large batches use)
