@@ -329,7 +329,7 @@ def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
     a.debug_enable(True), b.debug_enable(True)
     ia, ib = a.encode(leaves), b.encode(leaves)
     assert np.array_equal(ia, ib)
-    for name in ("e_a1", "e_y4", "e_a6", "e_x7", "e_y9", "e_x11") if n <= 20000 else ("e_x7", "e_x11"):
+    for name in ("e_y1", "e_a1", "e_y4", "e_a6", "e_x7", "e_y9", "e_x11") if n <= 20000 else ("e_x7", "e_x11"):
         c, p = DEBUG_SHAPES[name]
         assert np.array_equal(_bits(a.debug_fetch(name, n, c, p)), _bits(b.debug_fetch(name, n, c, p))), name
     if n <= 1024:
