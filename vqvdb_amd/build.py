@@ -12,8 +12,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vq_runtime.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "vq_kernels.h"), os.path.join(HERE, "csrc", "vq_device.h"),
-        os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip.h")]
+# every file of csrc/ is part of the one translation unit (vq_runtime.hip includes the kernel headers and vq_train_full.inc)
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".h", ".inc"))) + [
+    os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip.h")]
 LIB = os.path.join(HERE, "libvqvdb_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-value", "-Wno-unused-result"]
