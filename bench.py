@@ -4,18 +4,22 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over one 65,536-leaf batch per GPU, inputs resident in HBM
-(config 2 of BASELINE.json: "1xMI355X, 1M synthetic leaves, fp32 encoder+quantizer", i.e. 16
-steps of 64k leaves).  `value` is encode+quantize leaves/s over all ranks; the decode leg is
-timed the same way and reported under "decode".  Leaves shard across ranks with no data-path
-collective (weak scaling: per-GPU work is fixed).  PyTorch is used only for device memory,
-streams/events and the torch.distributed barrier.
+A step = one pass of the hot path over one 65,536-leaf batch per GPU, inputs resident in HBM.
+N = 1: BASELINE configs[1] ("1xMI355X, 1M synthetic leaves, fp32 encoder+quantizer" = 16 such batches, cycled for K steps).
+N > 1: BASELINE configs[3] ("leaves sharded across GPUs, 64M leaves" = 8 Mi leaves = 128 batches per GPU): the timed region
+       is max(K, 128) steps per rank so that every rank processes at least its configs[3] shard; `steps` in the JSON is the
+       number of steps really timed.
+`value` is encode+quantize leaves/s over all ranks; the decode leg is timed the same way and reported under "decode".
+Leaves shard across ranks with no data-path collective (weak scaling: per-GPU work is fixed).  PyTorch is used only for
+device memory, streams/events and the torch.distributed barrier.  Legs that go through host memory (end-to-end host-pointer
+calls, BASELINE configs[2] .vqvdb streaming decode) run in a PyTorch-free child process: vqvdb_amd/hostbench.py.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,13 +31,12 @@ sys.path.insert(0, ROOT)
 
 from vqvdb_amd import synth, weightpack  # noqa: E402
 from vqvdb_amd.codec import HipCodec  # noqa: E402
-from vqvdb_amd.sharding import max_over_ranks  # noqa: E402
+from vqvdb_amd.sharding import bind_rank_to_cpus, max_over_ranks, usable_cpus  # noqa: E402
 
 BATCH = 65536
+CONFIG3_LEAVES_PER_GPU = 8 * 1024 * 1024   # BASELINE configs[3]: 64 Mi leaves over 8 GPUs
 ENC_FLOP = 30_589_952      # nominal dense FLOP / leaf
 DEC_FLOP = 114_135_040
-ENC_FLOP_EFF = 22_869_760  # zero-padding taps excluded (informational)
-DEC_FLOP_EFF = 66_221_568
 PEAK_TF = 157.3            # fp32 MFMA dense peak per MI355X (MI355X_MICROARCH.md)
 
 
@@ -48,11 +51,12 @@ def timed(fn, steps, dist, device):
     if dist:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    return max_over_ranks(dt, device) if dist else dt
+    return (max_over_ranks(dt, device) if dist else dt), dt
 
 
-def profile_pass(codec, fn, steps, device, flop_key):
-    """Per-kernel averages from HIP events on the launch stream (library hook)."""
+def profile_pass(codec, fn, steps, device):
+    """Per-kernel averages from HIP events on the launch stream (library hook).  tflops_issued = FLOPs the kernel really
+    executes on the matrix pipe / time; tflops_nominal_dense = dense FLOP count of the reference ops it replaces / time."""
     codec.profile_enable(True)
     for s in range(steps):
         fn(s)
@@ -63,9 +67,10 @@ def profile_pass(codec, fn, steps, device, flop_key):
     for st in stats:
         avg_ms = st["total_ms"] / max(st["launches"], 1)
         leaves = st["leaves"] / max(st["launches"], 1)
+        tf = (lambda f: round(f * leaves / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0)
         out.append(dict(kernel=st["name"], avg_ms=round(avg_ms, 4), launches=st["launches"],
-                        tflops=round(st[flop_key] * leaves / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0,
-                        tflops_effective=round(st["eff_flops_per_leaf"] * leaves / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0))
+                        tflops_issued=tf(st["eff_flops_per_leaf"]), tflops_nominal_dense=tf(st["flops_per_leaf"]),
+                        issued_flop_per_leaf=st["eff_flops_per_leaf"], nominal_flop_per_leaf=st["flops_per_leaf"]))
     return out
 
 
@@ -80,67 +85,83 @@ def hbm_traffic(kernel):
         return None
 
 
-def roofline_of(kernels, total_flop_per_leaf, leaves_per_s_per_gpu):
+def roofline_of(kernels, nominal_flop_per_leaf, leaves_per_s_per_gpu):
+    """Roofline of the dominant kernel (longest average launch).  `achieved`/`frac` count the FLOPs the kernel ISSUES on the
+    matrix pipe (zero-padding taps are skipped, folded operators counted at their folded cost) — a true utilisation, <= 1, that
+    agrees with SQ_VALU_MFMA_BUSY x clock / 2.4 GHz from the PMC passes in profiles/.  The dense count of the reference ops the
+    kernel replaces is reported beside it as *_nominal_dense; it can exceed the peak and is not a utilisation."""
     dom = max(kernels, key=lambda k: k["avg_ms"])
+    issued_per_leaf = sum(k["issued_flop_per_leaf"] for k in kernels)
     return {
-        "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_TF, "unit": "TFLOP/s",
-        "frac": round(dom["tflops"] / PEAK_TF, 4), "traffic": hbm_traffic(dom["kernel"]),
-        "achieved_effective": dom["tflops_effective"], "avg_launch_ms": dom["avg_ms"],
-        "whole_path_frac": round(leaves_per_s_per_gpu * total_flop_per_leaf / (PEAK_TF * 1e12), 4),
-        "note": "achieved = nominal dense FLOP per leaf of the reference ops this kernel replaces (SURVEY App. A, padding taps counted) "
-                "x 65536 leaves / avg launch time; the kernels skip zero-padding taps (and fold/look up linear operators), so nominal can "
-                "exceed the MFMA peak; achieved_effective = FLOPs really issued on the matrix pipe / time (true utilisation); "
-                "whole_path_frac = leaves/s x nominal FLOP per leaf of the whole path / peak",
+        "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops_issued"], "peak": PEAK_TF, "unit": "TFLOP/s",
+        "frac": round(dom["tflops_issued"] / PEAK_TF, 4), "traffic": hbm_traffic(dom["kernel"]),
+        "avg_launch_ms": dom["avg_ms"], "flop_per_launch_issued": dom["issued_flop_per_leaf"] * BATCH,
+        "achieved_nominal_dense": dom["tflops_nominal_dense"], "ratio_nominal_dense_to_peak": round(dom["tflops_nominal_dense"] / PEAK_TF, 4),
+        "whole_path_frac": round(leaves_per_s_per_gpu * issued_per_leaf / (PEAK_TF * 1e12), 4),
+        "whole_path_issued_flop_per_leaf": issued_per_leaf,
+        "whole_path_ratio_nominal_dense_to_peak": round(leaves_per_s_per_gpu * nominal_flop_per_leaf / (PEAK_TF * 1e12), 4),
+        "note": "achieved = FLOPs issued on the matrix pipe per launch / average launch time (HIP events on the launch stream); frac = achieved / peak; "
+                "whole_path_frac = leaves/s x issued FLOP per leaf of every kernel of the pass / peak; *_nominal_dense = dense FLOP count of the reference ops "
+                "(SURVEY App. A, padding taps and folded operators counted in full) over the same times — what the algebraic eliminations buy, not a utilisation",
     }
 
 
-def usable_cpus() -> int:
-    """CPUs this process may really use: min(affinity mask, cgroup v2 cpu.max quota)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
 def cpu_baseline():
-    """CPU oracle (the repo's C restatement of the reference path, kind 'port') on a bounded sample:
-    the same uniform-random leaves as the GPU workload, repeated until ~10 s of CPU work per leg."""
+    """CPU oracle (the repo's C restatement of the reference path, kind 'port') on a bounded sample: the same uniform-random
+    leaves as the GPU workload, at all usable cores and at half of them (the reference's default: TorchBackend.cpp:74-78
+    sets at::set_num_threads(hardware_concurrency() / 2))."""
     from oracle.oracle import Oracle
     W = synth.make_weights(0)
     orc = Oracle(W, [t[0] for t in synth.TENSORS])
     threads = usable_cpus()
-    n = max(4096, min(16384, 256 * threads))
+    n = max(2048, min(16384, 256 * threads))
     leaves = synth.make_leaves(n, seed=1234)
 
-    def leg(fn, arg, budget=10.0):
-        t0 = time.perf_counter(); out = fn(arg, threads=threads); t1 = time.perf_counter() - t0
+    def leg(fn, arg, nthreads, budget):
+        t0 = time.perf_counter(); out = fn(arg, threads=nthreads); t1 = time.perf_counter() - t0
         reps = int(max(1, min(40, budget / max(t1, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(reps):
-            fn(arg, threads=threads)
+            fn(arg, threads=nthreads)
         return out, reps, time.perf_counter() - t0
 
-    idx, er, te = leg(orc.encode, leaves)
-    _, dr, td = leg(orc.decode, idx)
+    idx, er, te = leg(orc.encode, leaves, threads, 8.0)
+    _, dr, td = leg(orc.decode, idx, threads, 8.0)
+    half = max(1, threads // 2)
+    _, er2, te2 = leg(orc.encode, leaves, half, 5.0)
+    _, dr2, td2 = leg(orc.decode, idx, half, 5.0)
     return {"value": round(n * er / te, 1), "unit": "leaves/s", "cores": threads, "kind": "port",
-            "sample": f"{er} x {n} uniform-random leaves encode+quantize ({te:.1f} s) and {dr} x {n} decode ({td:.1f} s); "
-                      f"C oracle, OpenMP over 16-leaf tiles, {threads} threads "
-                      f"(= usable CPUs: affinity {len(os.sched_getaffinity(0))}, cgroup quota applied; {os.cpu_count()} visible)",
-            "decode_value": round(n * dr / td, 1)}, (leaves, idx)
+            "sample": f"{er} x {n} uniform-random leaves encode+quantize ({te:.1f} s) and {dr} x {n} decode ({td:.1f} s) at {threads} threads; "
+                      f"{er2} x {n} encode ({te2:.1f} s) and {dr2} x {n} decode ({td2:.1f} s) at {half} threads; "
+                      f"C oracle, OpenMP over 16-leaf tiles "
+                      f"(usable CPUs: affinity {len(os.sched_getaffinity(0))}, cgroup quota applied; {os.cpu_count()} visible)",
+            "decode_value": round(n * dr / td, 1),
+            "cores_half": half, "value_half_cores": round(n * er2 / te2, 1), "decode_value_half_cores": round(n * dr2 / td2, 1),
+            "half_cores_note": "the reference's libtorch CPU backend defaults to hardware_concurrency()/2 threads (src/backends/torch/TorchBackend.cpp:74-78)"}
+
+
+def host_legs(args):
+    """End-to-end host-memory legs in a PyTorch-free child process (vqvdb_amd/hostbench.py): host_path + BASELINE configs[2]."""
+    cmd = [sys.executable, "-m", "vqvdb_amd.hostbench", "--file-leaves", str(args.file_leaves), "--reps", "3"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"hostbench rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001 — never take the headline measurement down
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the codebook-training leg (BASELINE configs[4], quantizer part)")
-    ap.add_argument("--host-path", action="store_true", help="also time the host-pointer C ABI (pageable memory in/out, PCIe included)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training legs (BASELINE configs[4])")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory legs (host-pointer C ABI end to end; configs[2] .vqvdb streaming decode)")
+    ap.add_argument("--file-leaves", type=int, default=4 * 1024 * 1024, help="leaves in the configs[2] .vqvdb file")
     args = ap.parse_args()
 
     # Only the final JSON line may reach stdout.  Native libraries (RCCL prints its version banner with
@@ -153,29 +174,54 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # Rehearsal of the N > 1 code path on a box with ONE GPU (tests/tools only): every rank uses cuda:0 and the process
     # group runs on gloo (RCCL refuses two ranks on one device).  The numbers of such a run are meaningless.
     rehearsal = os.environ.get("VQ_BENCH_SINGLE_GPU_REHEARSAL") == "1"
-    if rehearsal:
-        local = 0
+    dev_index = 0 if rehearsal else local
     dist = world > 1 or os.environ.get("VQ_BENCH_FORCE_DIST") == "1"   # the latter exercises the RCCL path with one rank
+    if not dist and args.gpus != 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    device = torch.device("cuda", dev_index)
+    torch.cuda.set_device(device)
+    # one rank = one GPU = its own slice of the host's cores (NUMA node of the GPU when the topology is readable): the host-side
+    # copy threads of N ranks must not pile onto the same cores
+    affinity = None
+    if world > 1 and not rehearsal:
+        try:
+            affinity = bind_rank_to_cpus(local, local_world, pci_bus_id=getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+                                         pci_domain_id=getattr(torch.cuda.get_device_properties(device), "pci_domain_id", 0))
+        except Exception as e:  # noqa: BLE001 — binding is an optimisation, never a reason to fail
+            affinity = {"error": f"{type(e).__name__}: {e}"}
     if dist:
         if rehearsal:
             torch.distributed.init_process_group("gloo")
         else:
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-    elif args.gpus != 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+            torch.distributed.init_process_group("nccl", device_id=device)
+    # what the collective library really saw: an all-reduce of ones over the group, and each rank's device
+    backend, ranks_seen, devices_seen = None, 1, [torch.cuda.get_device_name(device)]
+    if dist:
+        backend = torch.distributed.get_backend()
+        one = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
+        objs = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(objs, {"rank": rank, "local_rank": local, "device": dev_index, "name": torch.cuda.get_device_name(device),
+                                                   "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+                                                   "cpus": (affinity or {}).get("cpus_bound")})
+        devices_seen = objs
+        assert ranks_seen == world == torch.distributed.get_world_size(), (ranks_seen, world)
 
     W = synth.make_weights(0)
-    codec = HipCodec(weightpack.dumps(W), device_id=local)
+    codec = HipCodec(weightpack.dumps(W), device_id=dev_index)
     codec.set_chunk_leaves(BATCH)
+
+    # N > 1: every rank covers at least its configs[3] shard (8 Mi leaves = 128 batches)
+    steps = args.steps if world == 1 else max(args.steps, CONFIG3_LEAVES_PER_GPU // BATCH)
 
     # synthetic leaves, uniform [0,1) (training data is [0,1]-normalised), resident in HBM; each
     # rank gets its own shard (different seed) -> no data-path collective.
-    nb = min(args.steps, 16)
+    nb = min(steps, 16)
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     leaves = [torch.rand(BATCH, 512, device=device, dtype=torch.float32, generator=gen) for _ in range(nb)]
@@ -195,10 +241,18 @@ def main():
         enc(s)
     for s in range(max(args.warmup, 1)):
         dec(s)
-    t_enc = timed(enc, args.steps, dist, device)
-    t_dec = timed(dec, args.steps, dist, device)
-    enc_lps = world * args.steps * BATCH / t_enc
-    dec_lps = world * args.steps * BATCH / t_dec
+    t_enc, t_enc_local = timed(enc, steps, dist, device)
+    t_dec, t_dec_local = timed(dec, steps, dist, device)
+    enc_lps = world * steps * BATCH / t_enc
+    dec_lps = world * steps * BATCH / t_dec
+    per_rank = None
+    if dist:   # every rank's own rate (its own clock around its own steps): min / max show stragglers
+        objs = [None] * world
+        torch.distributed.all_gather_object(objs, (steps * BATCH / t_enc_local, steps * BATCH / t_dec_local))
+        per_rank = {"encode_leaves_per_s": [round(o[0], 1) for o in objs], "decode_leaves_per_s": [round(o[1], 1) for o in objs],
+                    "encode_min_max": [round(min(o[0] for o in objs), 1), round(max(o[0] for o in objs), 1)],
+                    "decode_min_max": [round(min(o[1] for o in objs), 1), round(max(o[1] for o in objs), 1)],
+                    "note": "leaves/s of each rank over its own wall time for the timed steps (barriers included); value uses the slowest rank's time"}
 
     # Small-batch latency (position-split kernels): what the SOP's per-batch calls see (default 64, max 1024 encode / 8192
     # decode leaves, SOP_VQVDB_Encoder.cpp:33-38).  Device-resident, rank 0 only.
@@ -209,11 +263,13 @@ def main():
             for _ in range(3):
                 codec.encode_device(leaves[0].data_ptr(), nsm, idx[0].data_ptr(), stream)
                 codec.decode_device(idx[0].data_ptr(), nsm, rec.data_ptr(), stream)
-            t_e = timed(lambda s: codec.encode_device(leaves[0].data_ptr(), nsm, idx[0].data_ptr(), stream), 10, False, device)
-            t_d = timed(lambda s: codec.decode_device(idx[0].data_ptr(), nsm, rec.data_ptr(), stream), 10, False, device)
+            t_e, _ = timed(lambda s: codec.encode_device(leaves[0].data_ptr(), nsm, idx[0].data_ptr(), stream), 10, False, device)
+            t_d, _ = timed(lambda s: codec.decode_device(idx[0].data_ptr(), nsm, rec.data_ptr(), stream), 10, False, device)
             small[f"leaves_{nsm}"] = {"encode_ms": round(t_e / 10 * 1e3, 4), "decode_ms": round(t_d / 10 * 1e3, 4),
                                       "encode_leaves_per_s": round(nsm * 10 / t_e, 1), "decode_leaves_per_s": round(nsm * 10 / t_d, 1)}
         enc(0)   # idx[0] back to the full batch's indices for the parity spot check below
+
+    coll = (lambda nfl: f"all_reduce(SUM) of {nfl} fp32 over {world} rank(s), {'RCCL' if backend == 'nccl' else backend}") if dist else (lambda nfl: "none (1 rank)")
 
     # Codebook (EMA) training steps, the quantizer part of BASELINE configs[4]: per-rank batches of 2048 leaves (the
     # reference's BATCH_SIZE, python/training.py:49) and of 65536 leaves; statistics all-reduced over RCCL when N > 1.
@@ -221,23 +277,22 @@ def main():
     if not args.no_train:
         try:
             from vqvdb_amd.codebook_training import CodebookTrainer
-            tcodec = HipCodec(weightpack.dumps(W), device_id=local)   # its own handle: training rewrites the codebook
+            tcodec = HipCodec(weightpack.dumps(W), device_id=dev_index)   # its own handle: training rewrites the codebook
             tcodec.set_chunk_leaves(BATCH)
             trainer = CodebookTrainer(tcodec, device=str(device))
             train = {"note": "VectorQuantizerEMA training-mode step on encoder outputs (encoder forward + latent + assign + "
                              "statistics + all-reduce + EMA update); encoder/decoder weights frozen; not the headline value",
-                     "collective": (f"all_reduce(SUM) of 33281 fp32 over {world} rank(s), "
-                                    f"{'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()}") if dist else "none (1 rank)"}
+                     "collective": coll(33281)}
             ksteps = max(2, min(args.steps, 8))
-            for per_rank in (2048, BATCH):
-                x = leaves[0][:per_rank]
+            for per_rank_b in (2048, BATCH):
+                x = leaves[0][:per_rank_b]
                 for _ in range(2):
                     trainer.step(x, want_metrics=False)
-                t_tr = timed(lambda s: trainer.step(x, want_metrics=False), ksteps, dist, device)
+                t_tr, _ = timed(lambda s: trainer.step(x, want_metrics=False), ksteps, dist, device)
                 last = trainer.step(x)
-                train[f"per_rank_batch_{per_rank}"] = {"leaves_per_s": round(world * ksteps * per_rank / t_tr, 1),
-                                                        "ms_per_step": round(t_tr / ksteps * 1e3, 4), "steps": ksteps,
-                                                        "vq_loss": round(last["vq_loss"], 6), "perplexity": round(last["perplexity"], 3)}
+                train[f"per_rank_batch_{per_rank_b}"] = {"leaves_per_s": round(world * ksteps * per_rank_b / t_tr, 1),
+                                                          "ms_per_step": round(t_tr / ksteps * 1e3, 4), "steps": ksteps,
+                                                          "vq_loss": round(last["vq_loss"], 6), "perplexity": round(last["perplexity"], 3)}
             tcodec.close()
         except Exception as e:  # noqa: BLE001 — the training leg must never take the headline measurement down
             train = {"error": f"{type(e).__name__}: {e}"}
@@ -248,36 +303,35 @@ def main():
     if not args.no_train:
         try:
             from vqvdb_amd.full_training import FullTrainer
-            fcodec = HipCodec(weightpack.dumps(W), device_id=local)
+            fcodec = HipCodec(weightpack.dumps(W), device_id=dev_index)
             ftr = FullTrainer(fcodec, device=str(device))
             full = {"note": "one optimizer step = training-mode forward (unfolded decoder) + backward of every layer + all-reduce + AdamW + EMA "
                             "codebook update + rebuild of the weight-derived tables, fp32; not the headline value",
-                    "collective": (f"all_reduce(SUM) of 995905 + 33284 fp32 over {world} rank(s), "
-                                   f"{'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()}") if dist else "none (1 rank)",
+                    "collective": coll("995905 + 33284"),
                     "flop_per_leaf_nominal": 3 * (ENC_FLOP + DEC_FLOP)}
             ksteps = max(2, min(args.steps, 6))
-            for per_rank in (2048, 8192):
-                x = leaves[0][:per_rank]
+            for per_rank_b in (2048, 8192):
+                x = leaves[0][:per_rank_b]
                 for _ in range(2):
                     ftr.step(x, want_metrics=False)
-                t_ft = timed(lambda s: ftr.step(x, want_metrics=False), ksteps, dist, device)
+                t_ft, _ = timed(lambda s: ftr.step(x, want_metrics=False), ksteps, dist, device)
                 last = ftr.step(x)
-                lps = world * ksteps * per_rank / t_ft
-                full[f"per_rank_batch_{per_rank}"] = {"leaves_per_s": round(lps, 1), "ms_per_step": round(t_ft / ksteps * 1e3, 4), "steps": ksteps,
-                                                       "loss": round(last["loss"], 6), "perplexity": round(last["perplexity"], 3),
-                                                       "frac_of_fp32_mfma_peak_nominal": round(lps / world * 3 * (ENC_FLOP + DEC_FLOP) / (PEAK_TF * 1e12), 4)}
+                lps = world * ksteps * per_rank_b / t_ft
+                full[f"per_rank_batch_{per_rank_b}"] = {"leaves_per_s": round(lps, 1), "ms_per_step": round(t_ft / ksteps * 1e3, 4), "steps": ksteps,
+                                                         "loss": round(last["loss"], 6), "perplexity": round(last["perplexity"], 3),
+                                                         "ratio_nominal_dense_to_fp32_mfma_peak": round(lps / world * 3 * (ENC_FLOP + DEC_FLOP) / (PEAK_TF * 1e12), 4)}
             fcodec.close()
         except Exception as e:  # noqa: BLE001 — never take the headline measurement down
             full = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        ek = profile_pass(codec, enc, min(args.steps, 4), device, "flops_per_leaf")
-        dk = profile_pass(codec, dec, min(args.steps, 4), device, "flops_per_leaf")
+        ek = profile_pass(codec, enc, min(steps, 4), device)
+        dk = profile_pass(codec, dec, min(steps, 4), device)
         # spot parity: first 64 leaves of batch 0 vs the CPU oracle
         parity = None
         cpu = None
         if not args.no_cpu_baseline:
-            cpu, _ = cpu_baseline()
+            cpu = cpu_baseline()
             from oracle.oracle import Oracle
             orc = Oracle(W, [t[0] for t in synth.TENSORS])
             h = leaves[0][:64].cpu().numpy()
@@ -287,35 +341,41 @@ def main():
             oi = orc.encode(h, threads=usable_cpus())
             parity = f"{int((gi == oi).all(axis=1).sum())}/64 sampled leaves index-exact vs CPU oracle"
         host = None
-        if args.host_path:
-            nh = 8 * BATCH
-            hl = np.tile(leaves[0].cpu().numpy(), (8, 1))
-            codec.encode(hl[:BATCH])
-            t0 = time.perf_counter(); hi = codec.encode(hl); te = time.perf_counter() - t0
-            codec.decode(hi[:BATCH])
-            t0 = time.perf_counter(); codec.decode(hi); td = time.perf_counter() - t0
-            host = {"note": "host-pointer entry points (vqhip_encode/vqhip_decode), pageable host memory in and out, PCIe included; "
-                            "never the headline value", "leaves": nh, "encode_leaves_per_s": round(nh / te, 1), "decode_leaves_per_s": round(nh / td, 1)}
+        if world == 1 and not args.no_host_path:
+            # free this process's big buffers first: the child holds its own workspace and an 8 GB leaf pool
+            torch.cuda.synchronize(device)
+            host = host_legs(args)
+        elif world > 1:
+            host = {"skipped": "host-memory legs run at N = 1 only (one process per GPU already saturates its PCIe link)"}
         out = {
             "metric": "8^3 leaves/s encode+quantize (decode reported under 'decode')",
-            "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(t_enc / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(t_enc / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: 1xMI355X, 1M synthetic leaves in 65536-leaf batches, fp32 encoder+quantizer, K=256 D=128" if world == 1 else
-                                    f"BASELINE configs[3] shape: {world}xMI355X encode, leaves sharded across GPUs (65536-leaf batches per GPU per step), "
-                                    "fp32 encoder+quantizer, K=256 D=128"),
-                       "leaves_per_step_per_gpu": BATCH, "sharding": f"leaves sharded over {world} rank(s), no collective"},
+            "config": {"workload": (f"BASELINE configs[1]: 1xMI355X, 1M synthetic leaves (16 x 65536-leaf batches, cycled for {steps} steps), fp32 encoder+quantizer, K=256 D=128" if world == 1 else
+                                    f"BASELINE configs[3]: {world}xMI355X encode, leaves sharded across GPUs, {steps * BATCH} leaves per GPU "
+                                    f"(>= the 8 Mi-leaf shard of the 64M-leaf job; 65536-leaf batches), fp32 encoder+quantizer, K=256 D=128"),
+                       "leaves_per_step_per_gpu": BATCH, "leaves_per_gpu": steps * BATCH, "steps_requested": args.steps,
+                       "sharding": f"leaves sharded over {world} rank(s), no data-path collective"},
+            "collective_backend": ("nccl (RCCL)" if backend == "nccl" else backend) if dist else None,
+            "ranks_seen": ranks_seen,
+            "devices_seen": devices_seen,
+            "per_rank": per_rank,
+            "cpu_affinity": affinity,
             "roofline": roofline_of(ek, ENC_FLOP, enc_lps / world),
             "cpu_baseline": cpu,
             "decode": {
-                "value": round(dec_lps, 1), "unit": "leaves/s", "ms_per_step": round(t_dec / args.steps * 1e3, 4),
-                "workload": "BASELINE configs[2] kernel path: decode of 65536-leaf index batches resident in HBM",
+                "value": round(dec_lps, 1), "unit": "leaves/s", "ms_per_step": round(t_dec / steps * 1e3, 4),
+                "workload": "decode of 65536-leaf index batches resident in HBM (kernel path of BASELINE configs[2]; the file-level run is under 'config3')",
                 "roofline": roofline_of(dk, DEC_FLOP, dec_lps / world),
             },
             "kernels": {"encode": ek, "decode": dk},
-            "flop_per_leaf": {"encode_nominal": ENC_FLOP, "encode_effective": ENC_FLOP_EFF, "decode_nominal": DEC_FLOP, "decode_effective": DEC_FLOP_EFF},
+            "flop_per_leaf": {"encode_nominal_dense": ENC_FLOP, "decode_nominal_dense": DEC_FLOP,
+                              "encode_issued": sum(k["issued_flop_per_leaf"] for k in ek), "decode_issued": sum(k["issued_flop_per_leaf"] for k in dk)},
             "parity_sample": parity,
-            "host_path": host,
+            "host_path": (host or {}).get("host_path") if host and "host_path" in host else host,
+            "config3": (host or {}).get("config3"),
+            "host_process": (host or {}).get("process"),
             "codebook_training": train,
             "full_training": full,
             "small_batch": small,

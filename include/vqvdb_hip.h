@@ -208,6 +208,10 @@ int vqhip_fulltrain_apply_device(vqhip_codec* codec, const float* grads_dev, con
 /* host copies of the flat parameter vector (checkpoints, export to a weight pack); set also rebuilds the device tables */
 int vqhip_fulltrain_get_params(vqhip_codec* codec, float* params);
 int vqhip_fulltrain_set_params(vqhip_codec* codec, const float* params);
+/* AdamW moments (param_count floats each, flat parameter order) so that a checkpoint resumes the optimizer like the reference's
+ * does (python/training.py:216-226 saves optimizer and scheduler state); the step count is the caller's (apply_device's `step`). */
+int vqhip_fulltrain_get_opt_state(vqhip_codec* codec, float* exp_avg, float* exp_avg_sq);
+int vqhip_fulltrain_set_opt_state(vqhip_codec* codec, const float* exp_avg, const float* exp_avg_sq);
 
 /* ---- measurement hooks (bench.py / tests) ---- */
 

@@ -13,7 +13,10 @@
 #include "core/IVQVAECodec.hpp"
 #endif
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 

@@ -285,6 +285,35 @@ def test_config2_one_million_leaves_permutation_property(codec, oracle):
     assert np.array_equal(_bits(rec), _bits(base_rec[perm[:200_000]]))
 
 
+def test_config3_four_million_leaf_file_streamed_decode(codec, oracle, tmp_path):
+    """BASELINE configs[2] at full size: a single-grid .vqvdb of 4 Mi leaves decoded by vqhip_decompress_file in 65 536-leaf
+    batches (reference path: src/orchestrator/VQVAECodec.cpp:137-208, src/Utils/VQVDB_Reader.cpp:240-335).  Leaves are independent,
+    so the file is built from 4096 distinct index rows whose decodes are checked bit-exactly against the oracle; every one of the
+    4 Mi decoded leaves must then equal the decode of its row, and the origins must come back in file order."""
+    from vqvdb_amd import hostbench
+    n = 4 * 1024 * 1024
+    rng = np.random.default_rng(2024)
+    base_idx = rng.integers(0, 256, size=(4096, 64), dtype=np.uint8)
+    base_idx[:1024] = codec.encode(synth.make_leaves(1024, seed=99))          # realistic rows (encoder outputs) among the random ones
+    base_rec = codec.decode(base_idx)
+    assert np.array_equal(_bits(base_rec), _bits(oracle.decode(base_idx, threads=16)))
+    perm = rng.integers(0, 4096, size=n).astype(np.int32)
+    path = tmp_path / "c3.vqvdb"
+    hostbench.write_index_file(str(path), lambda s, k: base_idx[perm[s:s + k]], n)
+    assert path.stat().st_size == 12 + 4 + 7 + 64 + 6 + 4 + 76 * n
+    pool = np.empty((n, 512), dtype=np.float32)
+    grids, st = codec.decompress_file(path, batch_leaves=65536, out=pool)
+    assert st["leaves"] == n and st["grids"] == 1 and len(grids) == 1 and grids[0][0] == "density"
+    assert np.array_equal(grids[0][2], hostbench.origins_of(n))               # origins, file order
+    assert grids[0][3].shape == (n, 512) and grids[0][3].ctypes.data == pool.ctypes.data
+    bad = 0
+    for s in range(0, n, 1 << 18):
+        bad += int((_bits(pool[s:s + (1 << 18)]) != _bits(base_rec[perm[s:s + (1 << 18)]])).any(axis=1).sum())
+    assert bad == 0, f"{bad} of {n} leaves differ from the decode of their index row"
+    print(f"config3: {n} leaves in {st['wall_s']:.3f} s = {n / st['wall_s'] / 1e6:.2f} M leaves/s "
+          f"(read {st['read_s']:.3f} s, alloc {st['alloc_s']:.3f} s, scatter {st['copy_s']:.3f} s, waited for reader {st['io_wait_s']:.3f} s)")
+
+
 def test_leaf_pointer_entry_points(pack):
     """scattered per-leaf buffers in, scattered per-leaf buffers out, across chunk boundaries."""
     c = HipCodec(pack)
@@ -365,12 +394,18 @@ def test_bench_two_rank_code_path_rehearsal():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["decode"]["value"] > 0
+    # N > 1 = BASELINE configs[3]: every rank covers its 8 Mi-leaf shard (128 batches) even when fewer steps were asked for
+    assert d["steps"] == 128 and d["config"]["steps_requested"] == 2 and d["config"]["leaves_per_gpu"] == 8 * 1024 * 1024
+    assert d["ranks_seen"] == 2 and d["collective_backend"] == "gloo" and len(d["devices_seen"]) == 2
+    assert len(d["per_rank"]["encode_leaves_per_s"]) == 2 and d["per_rank"]["encode_min_max"][0] > 0
+    assert 0 < d["roofline"]["frac"] <= 1 and 0 < d["decode"]["roofline"]["frac"] <= 1
+    assert 0 < d["roofline"]["whole_path_frac"] <= 1 and 0 < d["decode"]["roofline"]["whole_path_frac"] <= 1
     ct = d["codebook_training"]
     assert "error" not in ct and "over 2 rank(s)" in ct["collective"] and ct["per_rank_batch_2048"]["leaves_per_s"] > 0
 

@@ -131,3 +131,79 @@ def test_full_training_host_helpers(weights):
         assert math.isclose(ft.cosine_lr(1e-4, step, 50), sch.get_last_lr()[0], rel_tol=1e-9, abs_tol=1e-15)
         opt.step()
         sch.step()
+
+
+def _patch_entry(pack: bytes, name: str, **fields) -> bytes:
+    """Rewrite fields (off / count / dims) of one table entry of a VQWPACK1 blob."""
+    buf = bytearray(pack)
+    n = weightpack._HEAD.unpack_from(buf, 0)[1]
+    for i in range(n):
+        pos = weightpack._HEAD.size + i * weightpack._ENTRY.size
+        rec = list(weightpack._ENTRY.unpack_from(buf, pos))
+        if rec[0].rstrip(b"\0").decode() == name:
+            if "off" in fields:
+                rec[8] = fields["off"]
+            if "count" in fields:
+                rec[9] = fields["count"]
+            buf[pos:pos + weightpack._ENTRY.size] = weightpack._ENTRY.pack(*rec)
+            return bytes(buf)
+    raise KeyError(name)
+
+
+def test_malformed_weight_pack_bounds_are_checked_before_any_read(weights):
+    """a user-supplied pack must not make vqhip_create read out of bounds — count/offset overflow, and a table entry
+    whose count disagrees with its dims (consumers read prod(dims) floats).  parse_pack runs before any device is touched."""
+    pack = weightpack.dumps(weights)
+    cases = {
+        "count overflows u64 when multiplied by 4": dict(count=(1 << 62) + 5),
+        "offset beyond the file": dict(off=(1 << 63)),
+        "offset + count wraps": dict(off=len(pack) - 4, count=(1 << 62)),
+    }
+    for what, f in cases.items():
+        with pytest.raises(RuntimeError, match="out of bounds"):
+            vc.HipCodec(_patch_entry(pack, "decoder.up_conv.weight", **f))
+    with pytest.raises(RuntimeError, match="count does not match its shape"):     # right dims, short count
+        vc.HipCodec(_patch_entry(pack, "decoder.up_conv.weight", count=16))
+    with pytest.raises(RuntimeError, match="count does not match its shape"):
+        vc.HipCodec(_patch_entry(pack, "encoder.pre.0.bias", count=17))
+
+
+def test_python_wrappers_validate_leaf_buffers():
+    ok = [np.zeros(512, np.float32) for _ in range(3)]
+    assert len(vc.HipCodec._leaf_ptrs(ok, 3, writable=True)) == 3
+    for bad in ([np.zeros(512, np.float64)] * 3, [np.zeros(511, np.float32)] * 3, [np.zeros((512, 2), np.float32)[:, 0]] * 3, ok[:2]):
+        with pytest.raises(ValueError):
+            vc.HipCodec._leaf_ptrs(bad, 3, writable=False)
+    ro = np.zeros(512, np.float32)
+    ro.flags.writeable = False
+    with pytest.raises(ValueError):
+        vc.HipCodec._leaf_ptrs([ro], 1, writable=True)
+
+
+def test_rank_cpu_plan_is_a_partition():
+    from vqvdb_amd.sharding import _parse_cpulist, plan_rank_cpus
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(96))
+    sets = [plan_rank_cpus(allowed, r, 8) for r in range(8)]
+    assert all(len(s) == 12 for s in sets) and sorted(sum(sets, [])) == allowed
+    # two NUMA nodes, four GPUs each: ranks sharing a node split that node's cores
+    node1 = list(range(48, 96))
+    s = [plan_rank_cpus(allowed, 4 + k, 8, node1, 4, k) for k in range(4)]
+    assert sorted(sum(s, [])) == node1
+    # fewer CPUs than ranks (a 2-CPU container): no binding rather than an empty set
+    assert plan_rank_cpus([0, 1], 5, 8) == [0, 1]
+    # NUMA node outside the allowed mask: falls back to the even split
+    assert plan_rank_cpus(list(range(16)), 1, 2, list(range(64, 128)), 1, 0) == list(range(8, 16))
+
+
+def test_hostbench_index_file_writer_matches_numpy_framing(tmp_path):
+    """The chunked single-grid writer used for the multi-million-leaf configs[2] files produces the App. B bytes."""
+    from vqvdb_amd import hostbench, vqvdbfile
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 256, size=(1000, 64), dtype=np.uint8)
+    p = tmp_path / "w.vqvdb"
+    hostbench.write_index_file(str(p), lambda s, k: idx[s:s + k], 1000, chunk=333)
+    want = vqvdbfile.dumps([vqvdbfile.Grid("density", hostbench.origins_of(1000), idx)])
+    assert p.read_bytes() == want
+    g = vqvdbfile.loads(p.read_bytes())[0]
+    assert len(np.unique(g.origins, axis=0)) == 1000

@@ -93,6 +93,7 @@ ABI_SYMBOLS = [
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
     "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
+    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -234,10 +235,21 @@ class HipCodec:
         self._check(self._lib.vqhip_decode(self._h, indices.ctypes.data, indices.shape[0], out.ctypes.data))
         return out
 
+    @staticmethod
+    def _leaf_ptrs(leaf_arrays: Sequence[np.ndarray], n: int, writable: bool):
+        """Addresses of n per-leaf buffers, each checked: float32, 512 elements, C-contiguous (the library reads / writes 2 KiB each)."""
+        if len(leaf_arrays) != n:
+            raise ValueError(f"expected {n} leaf buffers, got {len(leaf_arrays)}")
+        for i, a in enumerate(leaf_arrays):
+            if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.size != LEAF_VOXELS or not a.flags.c_contiguous \
+                    or (writable and not a.flags.writeable):
+                raise ValueError(f"leaf buffer {i}: need a C-contiguous{' writable' if writable else ''} float32 array of {LEAF_VOXELS} elements")
+        return (ctypes.c_void_p * n)(*[a.ctypes.data for a in leaf_arrays])
+
     def encode_leaves(self, leaf_arrays: Sequence[np.ndarray]) -> np.ndarray:
         """Leaf-pointer entry point: one 512-float buffer per leaf (e.g. OpenVDB leaf buffers)."""
         n = len(leaf_arrays)
-        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in leaf_arrays])
+        ptrs = self._leaf_ptrs(leaf_arrays, n, writable=False)
         idx = np.empty((n, LATENT_VOXELS), dtype=np.uint8)
         self._check(self._lib.vqhip_encode_leaves(self._h, ptrs, n, idx.ctypes.data))
         return idx
@@ -245,7 +257,7 @@ class HipCodec:
     def decode_leaves(self, indices: np.ndarray, leaf_arrays: Sequence[np.ndarray]) -> None:
         indices = np.ascontiguousarray(indices, dtype=np.uint8).reshape(-1, LATENT_VOXELS)
         n = indices.shape[0]
-        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in leaf_arrays])
+        ptrs = self._leaf_ptrs(leaf_arrays, n, writable=True)
         self._check(self._lib.vqhip_decode_leaves(self._h, indices.ctypes.data, n, ptrs))
 
     def compress_file(self, path, grids, batch_leaves: int = 0) -> dict:
@@ -263,6 +275,7 @@ class HipCodec:
             else:
                 if len(leaves) != n:
                     raise ValueError("one leaf buffer per origin")
+                self._leaf_ptrs(leaves, n, writable=False)   # validates every buffer
                 ptrs = np.array([a.ctypes.data for a in leaves], dtype=np.uint64)
             ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
             tr = None if transform is None else np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
@@ -277,10 +290,15 @@ class HipCodec:
         self._check(self._lib.vqhip_compress_file(self._h, os.fspath(path).encode(), src, n_g, batch_leaves, ctypes.byref(st)))
         return st.as_dict()
 
-    def decompress_file(self, path, batch_leaves: int = 0):
+    def decompress_file(self, path, batch_leaves: int = 0, out: Optional[np.ndarray] = None):
         """Whole-file decompress (vqhip_decompress_file).  Returns ([(name, transform[16], origins [n,3], leaves [n,512])], stats);
-        the leaf allocator hands out one fresh 2 KiB-per-leaf block per batch, the stand-in for tree.touchLeaf()."""
+        the leaf allocator hands out one fresh 2 KiB-per-leaf block per batch, the stand-in for tree.touchLeaf().
+        out: optional preallocated C-contiguous float32 [total_leaves, 512] pool — leaves of all grids are then placed in it in
+        file order (no per-batch allocation, no concatenation: multi-million-leaf files) and the returned leaf arrays are views."""
         grids, blocks = [], []
+        if out is not None and (out.dtype != np.float32 or out.ndim != 2 or out.shape[1] != LEAF_VOXELS or not out.flags.c_contiguous):
+            raise ValueError("out must be a C-contiguous float32 [n, 512] array")
+        cursor = [0]
 
         def on_grid(_user, gi):
             g = gi.contents
@@ -291,7 +309,13 @@ class HipCodec:
         def on_alloc(_user, gidx, origins, n, out_ptrs):
             try:
                 org = np.ctypeslib.as_array(origins, shape=(n, 3)).copy()
-                buf = np.empty((n, LEAF_VOXELS), dtype=np.float32)
+                if out is not None:
+                    if cursor[0] + n > out.shape[0]:
+                        raise ValueError(f"out holds {out.shape[0]} leaves, the file has more")
+                    buf = out[cursor[0]:cursor[0] + n]
+                    cursor[0] += n
+                else:
+                    buf = np.empty((n, LEAF_VOXELS), dtype=np.float32)
                 dst = np.ctypeslib.as_array(ctypes.cast(out_ptrs, ctypes.POINTER(ctypes.c_uint64)), shape=(n,))
                 dst[:] = buf.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(LEAF_VOXELS * 4)
                 blocks[gidx].append((org, buf))
@@ -306,7 +330,11 @@ class HipCodec:
         out = []
         for (name, tr, _total), bl in zip(grids, blocks):
             org = np.concatenate([b[0] for b in bl]) if bl else np.zeros((0, 3), np.int32)
-            lv = np.concatenate([b[1] for b in bl]) if bl else np.zeros((0, LEAF_VOXELS), np.float32)
+            if out is not None and bl:   # consecutive slices of the pool: one view, no copy
+                first = (bl[0][1].ctypes.data - out.ctypes.data) // (LEAF_VOXELS * 4)
+                lv = out[first:first + sum(len(b[1]) for b in bl)]
+            else:
+                lv = np.concatenate([b[1] for b in bl]) if bl else np.zeros((0, LEAF_VOXELS), np.float32)
             out.append((name, tr, org, lv))
         return out, st.as_dict()
 
@@ -341,6 +369,9 @@ class HipCodec:
 
     def train_set_state(self, embedding=None, cluster_size=None, embed_avg=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (embedding, cluster_size, embed_avg)]
+        for a, size, what in zip(arrs, (256 * 128, 256, 256 * 128), ("embedding", "cluster_size", "embed_avg")):
+            if a is not None and a.size != size:
+                raise ValueError(f"{what}: expected {size} float32 values, got {a.size}")
         self._check(self._lib.vqhip_train_set_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
     def train_commit(self):
@@ -379,6 +410,18 @@ class HipCodec:
         if flat.size != self.fulltrain_param_count():
             raise ValueError("flat parameter vector has the wrong length")
         self._check(self._lib.vqhip_fulltrain_set_params(self._h, flat.ctypes.data))
+
+    def fulltrain_get_opt_state(self):
+        """AdamW moments (exp_avg, exp_avg_sq), flat parameter order."""
+        m, v = np.empty(self.fulltrain_param_count(), np.float32), np.empty(self.fulltrain_param_count(), np.float32)
+        self._check(self._lib.vqhip_fulltrain_get_opt_state(self._h, m.ctypes.data, v.ctypes.data))
+        return m, v
+
+    def fulltrain_set_opt_state(self, exp_avg: np.ndarray, exp_avg_sq: np.ndarray):
+        m, v = (np.ascontiguousarray(a, dtype=np.float32) for a in (exp_avg, exp_avg_sq))
+        if m.size != self.fulltrain_param_count() or v.size != m.size:
+            raise ValueError("optimizer moments have the wrong length")
+        self._check(self._lib.vqhip_fulltrain_set_opt_state(self._h, m.ctypes.data, v.ctypes.data))
 
     def fetch(self, name: str, n: int, channels: int, positions: int) -> np.ndarray:
         """debug_fetch without the debug flag: any named workspace tensor as [n, channels, positions]."""

@@ -174,8 +174,18 @@ bool parse_pack(const unsigned char* p, size_t n, std::map<std::string, PackTens
         std::memcpy(dims, e + 68, 24);
         std::memcpy(&off, e + 92, 8);
         std::memcpy(&cnt, e + 100, 8);
-        if (ndim > 6 || off + cnt * 4 > n || (off & 3)) {
+        // overflow-safe bounds: off and cnt come from the (user-supplied) file
+        if (ndim > 6 || (off & 3) || off > n || cnt > (n - off) / 4) {
             err = std::string("weight pack: tensor '") + name + "' out of bounds";
+            return false;
+        }
+        uint64_t prod = 1;
+        for (uint32_t d = 0; d < ndim; ++d) {
+            if (dims[d] != 0 && prod > UINT64_MAX / dims[d]) prod = UINT64_MAX;
+            else prod *= dims[d];
+        }
+        if (prod != cnt) {   // every consumer reads prod(dims) floats from the tensor
+            err = std::string("weight pack: tensor '") + name + "' count does not match its shape";
             return false;
         }
         PackTensor t;
@@ -1194,31 +1204,41 @@ int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool w
         hipStreamSynchronize(c->s_out);
         return code;
     };
+    // inside the loop every error exit goes through abort_run: async copies may still reference caller / slot memory
+#define PIPECHK(call)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) {                                              \
+            c->err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            return abort_run(VQHIP_ERR_DEVICE);                              \
+        }                                                                    \
+    } while (0)
     for (int64_t o = 0; o < n; o += step, ++i) {
         const int64_t m = std::min(step, n - o);
         const int slot = i & 1;
         void* d_in = is_encode ? (void*)c->dev_leaves[slot] : (void*)c->dev_idx[slot];
         void* d_out = is_encode ? (void*)c->dev_idx[slot] : (void*)c->dev_leaves[slot];
-        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0));  // slot's previous input consumed
-        if (want_stage && i >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[slot]));  // the H2D that last read this pinned buffer is done
+        if (i >= 2) PIPECHK(hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0));  // slot's previous input consumed
+        if (want_stage && i >= 2) PIPECHK(hipEventSynchronize(c->ev_in[slot]));  // the H2D that last read this pinned buffer is done
         const void* src = produce(o, m, want_stage ? c->pin_in[slot] : nullptr);
         if (!src) return abort_run(c->err.empty() ? fail(c, VQHIP_ERR_INVALID, "input source failed") : VQHIP_ERR_INVALID);
-        HIPCHK(c, hipMemcpyAsync(d_in, src, (size_t)m * in_b, hipMemcpyHostToDevice, c->s_in));
-        HIPCHK(c, hipEventRecord(c->ev_in[slot], c->s_in));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
-        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[slot], 0));  // slot's previous output drained to pinned
+        PIPECHK(hipMemcpyAsync(d_in, src, (size_t)m * in_b, hipMemcpyHostToDevice, c->s_in));
+        PIPECHK(hipEventRecord(c->ev_in[slot], c->s_in));
+        PIPECHK(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+        if (i >= 2) PIPECHK(hipStreamWaitEvent(c->stream, c->ev_out[slot], 0));  // slot's previous output drained to pinned
         rc = is_encode ? encode_chunk(c, c->dev_leaves[slot], m, c->dev_idx[slot], c->stream)
                        : decode_chunk(c, c->dev_idx[slot], m, c->dev_leaves[slot], c->stream);
         if (rc) return abort_run(rc);
-        HIPCHK(c, hipEventRecord(c->ev_done[slot], c->stream));
+        PIPECHK(hipEventRecord(c->ev_done[slot], c->stream));
         if ((rc = drain())) return abort_run(rc);  // chunk i-1 -> caller, overlapped with chunk i on the GPU
-        HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_done[slot], 0));
-        HIPCHK(c, hipMemcpyAsync(c->pin_out[slot], d_out, (size_t)m * out_b, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(c, hipEventRecord(c->ev_out[slot], c->s_out));
+        PIPECHK(hipStreamWaitEvent(c->s_out, c->ev_done[slot], 0));
+        PIPECHK(hipMemcpyAsync(c->pin_out[slot], d_out, (size_t)m * out_b, hipMemcpyDeviceToHost, c->s_out));
+        PIPECHK(hipEventRecord(c->ev_out[slot], c->s_out));
         prev_off = o, prev_m = m, prev_slot = slot;
     }
     if ((rc = drain())) return abort_run(rc);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    PIPECHK(hipStreamSynchronize(c->stream));
+#undef PIPECHK
     return VQHIP_OK;
 }
 

@@ -143,6 +143,20 @@ class FullTrainer:
         self.codec.train_set_state(embedding=sd["quantizer.embedding"], cluster_size=sd.get("quantizer.cluster_size"),
                                    embed_avg=sd.get("quantizer.embed_avg"))
 
+    def checkpoint(self) -> dict:
+        """Everything a resumed run needs, like the reference's checkpoint (training.py:216-226: model, optimizer and scheduler
+        state): state_dict() + AdamW moments + the step count (bias correction and position on the cosine schedule)."""
+        ck = self.state_dict()
+        m, v = self.codec.fulltrain_get_opt_state()
+        ck.update({"optimizer.exp_avg": m, "optimizer.exp_avg_sq": v, "optimizer.steps_done": np.int64(self.steps_done)})
+        return ck
+
+    def load_checkpoint(self, ck: dict):
+        self.load_state_dict({k: v for k, v in ck.items() if not k.startswith("optimizer.")})
+        if "optimizer.exp_avg" in ck:
+            self.codec.fulltrain_set_opt_state(ck["optimizer.exp_avg"], ck["optimizer.exp_avg_sq"])
+            self.steps_done = int(ck["optimizer.steps_done"])
+
     def finish(self):
         """Rebuild what the inference path folds on the host (decoder tail, projection inside the VQ search, stem table)."""
         self.codec.train_commit()

@@ -4,6 +4,10 @@
 // outside the reference tree (tests, harness, bench); inside the reference tree the adapter
 // include/vqvdb_hip_backend.hpp includes the reference's own "core/IVQVAECodec.hpp".
 //
+// The declarations restate the interface of ZephirFXEC/VQVDB's src/core/IVQVAECodec.hpp (BSD-3-Clause,
+// Copyright (c) the VQVDB authors; see the upstream repository's LICENSE), which a drop-in backend has to
+// match name for name.
+//
 // The one addition is BackendType::HIP, appended so the existing enumerator values keep
 // their numbers.
 #pragma once

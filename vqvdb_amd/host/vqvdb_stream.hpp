@@ -111,6 +111,7 @@ class StreamReader {
 		GridMeta m;
 		uint32_t nameLen;
 		get(&nameLen, 4, "Failed to read grid name length.");
+		if (nameLen > (1u << 20)) throw std::runtime_error("Grid name length is implausible (corrupt file).");   // same cap as vqhip_decompress_file
 		m.name.resize(nameLen);
 		get(m.name.data(), nameLen, "Failed to read grid name.");
 		get(m.transform.data(), 64, "Failed to read transform.");

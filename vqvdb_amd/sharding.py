@@ -66,3 +66,82 @@ def gather_to_rank0(local: np.ndarray, n_total: int, rank: int, world: int) -> O
         lo, hi = shard_range(n_total, g, world)
         parts.append(bufs[g].numpy()[:hi - lo])
     return np.concatenate(parts)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _parse_cpulist(text: str) -> list:
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def plan_rank_cpus(allowed: list, local_rank: int, local_world: int, numa_cpus: Optional[list] = None, numa_peers: int = 1,
+                   numa_slot: int = 0) -> list:
+    """CPU set for one rank of `local_world` ranks on a node (pure function: tests/test_host_logic.py).
+
+    With the GPU's NUMA node known: the node's allowed CPUs, split evenly among the `numa_peers` ranks whose GPUs sit on the
+    same node (this rank being number `numa_slot` of them).  Otherwise: an even contiguous split of the allowed CPUs over the
+    local ranks.  Never returns an empty set: with fewer CPUs than ranks the whole allowed set is kept (no binding)."""
+    allowed = sorted(allowed)
+    if numa_cpus:
+        pool = [c for c in sorted(numa_cpus) if c in set(allowed)]
+        if len(pool) >= numa_peers >= 1:
+            per = len(pool) // numa_peers
+            return pool[numa_slot * per:(numa_slot + 1) * per]
+    if len(allowed) < local_world:
+        return allowed
+    per = len(allowed) // local_world
+    return allowed[local_rank * per:(local_rank + 1) * per]
+
+
+def bind_rank_to_cpus(local_rank: int, local_world: int, pci_bus_id=None, pci_domain_id: int = 0, gpu_numa_nodes: Optional[list] = None) -> dict:
+    """Pin this process (and the library's copy threads it will spawn) to its share of the host cores: the cores of the GPU's
+    NUMA node when /sys exposes it, an even split otherwise.  gpu_numa_nodes: NUMA node of every local rank's GPU, if the
+    caller gathered them (lets ranks that share a node split it); without it each rank takes its node's cores divided by
+    ceil(local_world / number of nodes).  Returns what was done (for the bench JSON)."""
+    import os
+    allowed = sorted(os.sched_getaffinity(0))
+    node, numa_cpus = None, None
+    if pci_bus_id is not None:
+        try:
+            dev = f"{int(pci_domain_id):04x}:{int(pci_bus_id):02x}:00.0"
+            node = int(open(f"/sys/bus/pci/devices/{dev}/numa_node").read())
+            if node >= 0:
+                numa_cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+        except (OSError, ValueError):
+            node, numa_cpus = None, None
+    peers, slot = 1, 0
+    if numa_cpus:
+        if gpu_numa_nodes:
+            same = [r for r, nd in enumerate(gpu_numa_nodes) if nd == node]
+            peers, slot = len(same), same.index(local_rank)
+        else:
+            try:
+                n_nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+            except OSError:
+                n_nodes = 1
+            peers = max(1, -(-local_world // max(n_nodes, 1)))
+            slot = local_rank % peers
+    cpus = plan_rank_cpus(allowed, local_rank, local_world, numa_cpus, peers, slot)
+    bound = False
+    if cpus and len(cpus) < len(allowed):
+        os.sched_setaffinity(0, cpus)
+        bound = True
+    return {"bound": bound, "cpus_bound": len(cpus), "first_cpu": cpus[0] if cpus else None, "numa_node": node,
+            "policy": "GPU's NUMA node" if numa_cpus else "even split of the allowed CPUs"}

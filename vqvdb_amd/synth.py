@@ -143,3 +143,40 @@ def edge_leaves() -> np.ndarray:
     e[6] = 0.5
     e[7] = make_leaves(1, seed=79)[0] * np.float32(1e-3)
     return e
+
+
+def sparse_leaves(n: int, seed: int = 2468) -> np.ndarray:
+    """``n`` leaves shaped like real VDB content rather than white noise ("real VDB leaves are sparse /
+    background-dominated"): mostly-background leaves with a smooth blob (fog-volume falloff), a narrow-band ramp across a
+    plane (level-set like, saturating at 0 / 1), background with a handful of active voxels, shifted and x5-scaled noise
+    (values outside [0,1]), near-constant leaves and exact zeros.  Leaf ``i`` depends only on ``(seed, i)``; float32
+    arithmetic with correctly rounded operations only (+ - * / sqrt, min / max), so it regenerates bit-identically."""
+    f = np.float32
+    u = uniform01(seed, 7, n * 16).reshape(n, 16)          # per-leaf parameters
+    noise = uniform01(seed, 8, n * 512).reshape(n, 512)
+    d, h, w = np.meshgrid(np.arange(8, dtype=np.float32), np.arange(8, dtype=np.float32), np.arange(8, dtype=np.float32), indexing="ij")
+    P = np.stack([d.reshape(-1), h.reshape(-1), w.reshape(-1)], axis=0)      # [3,512], offset d*64+h*8+w
+    out = np.zeros((n, 512), dtype=np.float32)
+    kind = u[:, 0]
+    for i in range(n):
+        k = kind[i]
+        if k < f(0.40):      # blob: clamp(1 - |p-c|/r, 0, 1) * amplitude, centre possibly outside the leaf
+            c = (u[i, 1:4] * f(14.0) - f(3.0)).reshape(3, 1)
+            r = f(2.0) + u[i, 4] * f(8.0)
+            dist = np.sqrt(((P - c) * (P - c)).sum(axis=0, dtype=np.float32))
+            out[i] = np.maximum(f(1.0) - dist / r, f(0.0)) * (f(0.25) + f(0.75) * u[i, 5])
+        elif k < f(0.60):    # narrow band across a plane: clamp(0.5 + (n.p - d)/w, 0, 1)
+            nv = (u[i, 1:4] * f(2.0) - f(1.0)).reshape(3, 1)
+            off = u[i, 4] * f(10.0) - f(1.5)
+            wd = f(0.75) + u[i, 5] * f(3.0)
+            out[i] = np.minimum(np.maximum(f(0.5) + ((nv * P).sum(axis=0, dtype=np.float32) - off) / wd, f(0.0)), f(1.0))
+        elif k < f(0.75):    # background + a handful of active voxels
+            cnt = 1 + int(u[i, 1] * f(8.0))
+            pos = (uniform01(seed, 9, cnt, start=i * 8) * f(512.0)).astype(np.int64) % 512
+            out[i, pos] = noise[i, :cnt]
+        elif k < f(0.85):    # shifted, x5-scaled noise: values in [-1, 4)
+            out[i] = noise[i] * f(5.0) - f(1.0)
+        elif k < f(0.95):    # near-constant leaf
+            out[i] = u[i, 1] + noise[i] * f(1e-4)
+        # else: exact zeros (pure background)
+    return out

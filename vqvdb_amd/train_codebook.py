@@ -86,6 +86,12 @@ def train(args) -> dict:
     # this rank's shard of every global batch, resident in HBM (2 KiB per leaf)
     gb = args.batch_size * world
     steps_per_epoch = len(tr_ids) // gb
+    # every rank sees the same sizes, so every rank raises here together (a rank with an empty shard would otherwise fail alone
+    # inside a step while its peers block in all_reduce)
+    if steps_per_epoch < 1:
+        raise SystemExit(f"training set of {len(tr_ids)} leaves is smaller than one global batch ({world} x {args.batch_size}); lower --batch-size")
+    if len(va_ids) < world:
+        raise SystemExit(f"validation set of {len(va_ids)} leaves cannot give each of the {world} ranks a leaf")
 
     def shard(ids, step):
         lo, hi = shard_range(gb, rank, world)
@@ -93,8 +99,15 @@ def train(args) -> dict:
 
     d_all = torch.from_numpy(np.ascontiguousarray(leaves)).to(device)
     best_val, history = float("inf"), []
+    start_epoch = 0
+    if args.resume:   # continue from a checkpoint written below: weights, quantizer buffers and (full mode) AdamW moments + step count
+        ck = dict(np.load(args.resume))
+        start_epoch = int(ck.pop("epoch", 0))
+        best_val = float(ck.pop("best_val_loss", best_val))
+        trainer.load_checkpoint(ck) if full else trainer.load_state_dict(ck)
+        log(f"Resumed from {args.resume} at epoch {start_epoch}")
     os.makedirs(os.path.dirname(os.path.abspath(args.model_path)) or ".", exist_ok=True)
-    for epoch in range(args.epochs):
+    for epoch in range(start_epoch, args.epochs):
         order = np.random.default_rng(args.seed + 1 + epoch).permutation(tr_ids)        # shuffle=True (training.py:87-94)
         t0 = time.perf_counter()
         tot_vq, last = 0.0, None
@@ -133,7 +146,8 @@ def train(args) -> dict:
             f"{rec['leaves_per_s'] / 1e6:.3f} M leaves/s ({dt:.2f} s/epoch)")
         if val_loss < best_val and rank == 0:
             best_val = val_loss
-            np.savez(args.model_path, epoch=epoch + 1, best_val_loss=best_val, **trainer.state_dict())
+            # full mode: optimizer moments and step count included (training.py:216-226), see FullTrainer.checkpoint
+            np.savez(args.model_path, epoch=epoch + 1, best_val_loss=best_val, **(trainer.checkpoint() if full else trainer.state_dict()))
             log(f"New best validation loss: {val_loss:.6f} - model saved.")
     trainer.finish()
     if rank == 0:
@@ -166,6 +180,7 @@ def main(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--log_every", type=int, default=100)
     p.add_argument("--model_path", type=str, default="models/quantizer.npz")
+    p.add_argument("--resume", type=str, default=None, help="checkpoint (.npz written as --model_path) to continue from")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     p.add_argument("--single_gpu_rehearsal", action="store_true", help="tests: every rank on cuda:0 (use with --backend gloo)")
     p.set_defaults(func=train)
