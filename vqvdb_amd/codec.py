@@ -162,6 +162,8 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_apply_device.argtypes = [vp, vp, vp, cf, i64, cf, cf, cf, cf, cf, cf, vp]
     lib.vqhip_fulltrain_get_params.argtypes = [vp, vp]
     lib.vqhip_fulltrain_set_params.argtypes = [vp, vp]
+    lib.vqhip_fulltrain_get_opt_state.argtypes = [vp, vp, vp]
+    lib.vqhip_fulltrain_set_opt_state.argtypes = [vp, vp, vp]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
     lib.vqhip_profile_read.argtypes = [vp, ctypes.POINTER(_KernelStat), ci, ctypes.POINTER(ci)]
     lib.vqhip_debug_enable.argtypes = [vp, ci]
@@ -178,6 +180,8 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_decompress_file.argtypes = [vp, ctypes.c_char_p, i64, GRID_BEGIN_FN, LEAF_ALLOC_FN, vp, ctypes.POINTER(StreamStats)]
     lib.vqhip_compress_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(_GridSource), ci, i64, ctypes.POINTER(StreamStats)]
     for name in ABI_SYMBOLS:
+        if getattr(lib, name).argtypes is None and name not in ("vqhip_version",):
+            raise RuntimeError(f"codec.py: no argtypes declared for {name} (pointers would be truncated to 32 bits)")
         if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error",
                         "vqhip_fulltrain_param_count"):
             getattr(lib, name).restype = ci
@@ -327,16 +331,16 @@ class HipCodec:
         cb_g, cb_a = GRID_BEGIN_FN(on_grid), LEAF_ALLOC_FN(on_alloc)
         st = StreamStats()
         self._check(self._lib.vqhip_decompress_file(self._h, os.fspath(path).encode(), batch_leaves, cb_g, cb_a, None, ctypes.byref(st)))
-        out = []
+        result = []
         for (name, tr, _total), bl in zip(grids, blocks):
             org = np.concatenate([b[0] for b in bl]) if bl else np.zeros((0, 3), np.int32)
-            if out is not None and bl:   # consecutive slices of the pool: one view, no copy
+            if out is not None and len(bl):   # consecutive slices of the pool: one view, no copy
                 first = (bl[0][1].ctypes.data - out.ctypes.data) // (LEAF_VOXELS * 4)
                 lv = out[first:first + sum(len(b[1]) for b in bl)]
             else:
                 lv = np.concatenate([b[1] for b in bl]) if bl else np.zeros((0, LEAF_VOXELS), np.float32)
-            out.append((name, tr, org, lv))
-        return out, st.as_dict()
+            result.append((name, tr, org, lv))
+        return result, st.as_dict()
 
     def encode_device(self, leaves_ptr: int, n: int, idx_ptr: int, stream: int = 0):
         self._check(self._lib.vqhip_encode_device(self._h, leaves_ptr, n, idx_ptr, stream or None))
