@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VQ_LT 32  // leaves per tile

@@ -13,6 +13,7 @@
 
 struct ConvArgs {
     const float* in;         // L4 activations [tile][NPI][CIN/4][32][4]
+    const float* zeros;      // >= 64 bytes of zeros (first conv: operand of the K pad slot)
     float* out;              // L4 activations [tile][NPO][COUT/4][32][4] (or pixel-shuffled)
     const float* wfrag;      // fragment-ordered weights
     const float* bias_frag;  // bias in D-fragment order (mfma32) or plain (mfma16)
@@ -71,9 +72,14 @@ __device__ __forceinline__ void glds16(const f32x4* gsrc_lane, f32x4* lds_wave_b
 }
 
 // ------------------------------------------------------------------------------------------
-// pack: host/leaf-major leaves [n][512] -> x[tile][512][32]   (VQVAECodec.cpp:36-59 layout in)
+// pack: host/leaf-major leaves [n][512] (VQVAECodec.cpp:36-59 layout in) ->
+//   xr[tile][row 64][leaf 32][12]   the first conv's input: one W-row of a leaf = (0, x0 .. x7, 0, -, -), halo zeros included, so
+//                                   that a lane reads its eight B operands x[ow + kw - 1] (ow = 0..7) as two 16-byte loads
+//   xt[tile][512][32]               position-major copy, only when `xt` != nullptr (training: loss and first-conv weight gradients)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ leaves, float* __restrict__ xt, int64_t n_leaves)
+#define VQ_XR_REC 12              // floats per (row, leaf) record of xr
+#define VQ_XR_TILE (64 * 32 * VQ_XR_REC)
+__global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ leaves, float* __restrict__ xr, float* __restrict__ xt, int64_t n_leaves)
 {
     __shared__ float tile[32][65];
     const int t = blockIdx.x;
@@ -88,9 +94,17 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
             tile[l][p] = leaf < n_leaves ? leaves[leaf * 512 + p0 + p] : 0.0f;
         }
         __syncthreads();
-        for (int i = tid; i < 32 * 64; i += 256) {
-            const int p = i >> 5, l = i & 31;
-            xt[((int64_t)t * 512 + p0 + p) * 32 + l] = tile[l][p];
+        if (xt) {
+            for (int i = tid; i < 32 * 64; i += 256) {
+                const int p = i >> 5, l = i & 31;
+                xt[((int64_t)t * 512 + p0 + p) * 32 + l] = tile[l][p];
+            }
+        }
+        // the chunk's 8 rows: 8 x 32 records of 12 floats, written as one contiguous run
+        float* dst = xr + (size_t)t * VQ_XR_TILE + (size_t)(p0 >> 3) * 32 * VQ_XR_REC;
+        for (int i = tid; i < 8 * 32 * VQ_XR_REC; i += 256) {
+            const int r = i / (32 * VQ_XR_REC), rem = i % (32 * VQ_XR_REC), l = rem / VQ_XR_REC, e = rem % VQ_XR_REC;
+            dst[i] = (e >= 1 && e <= 8) ? tile[l][r * 8 + e - 1] : 0.0f;
         }
         __syncthreads();
     }
@@ -101,8 +115,10 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
 // statistics of the result for ResidualBlock.gn1 (:205).
 // 16x16x4 MFMA: rows = 16 couts, cols = 16 leaves, K = (kd,kh) x {kw0,kw1,kw2,pad}.  A wave owns a
 // 32-leaf tile (two 16-leaf sub-tiles) and a full output row of 8 positions (16 independent
-// accumulators); one step = (output row, valid kd) = up to 3 kh x 16 MFMAs, the next step's 48 input
-// dwords are prefetched meanwhile.  The conv is so cheap (221 k MAC/leaf) that it is run TWICE instead
+// accumulators); one step = (output row, valid kd) = up to 3 kh x 16 MFMAs, the next step's input (3 rows x 2 sub-tiles x
+// two 16-byte loads from the row layout xr, see pack_leaves_k) is prefetched meanwhile.  Twelve wide loads per step instead of
+// 48 dword loads: the kernel used to be bound by the rate at which a CU accepts vector-memory instructions (ablations in
+// tools/ablate/conv_first_ablate.hip: 0.45 -> 0.32 ms for the statistics pass), not by its fp64 statistics.  The conv is so cheap (221 k MAC/leaf) that it is run TWICE instead
 // of materialising its 32 KiB/leaf output:
 //   MODE 0: statistics of y1 = conv(x)+bias for GroupNorm(4,16) (no activation store unless A.out != 0)
 //   MODE 1: recompute y1, a1 = relu(gn(y1)) -> store, statistics of a1 for GroupNorm(8,16).
@@ -119,17 +135,12 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = A.wfrag[t * 64 + lane];
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
-    const float* x = A.in + (size_t)tile * 512 * 32 + jj;
+    // K slot q4 = kw (3 = pad).  A lane's eight B operands of a row, x[ow + kw - 1] for ow = 0..7, are the 8 floats starting at
+    // element kw of the row's record (0, x0..x7, 0): two 16-byte loads at 4-byte alignment.  The pad slot reads a record of zeros
+    // (stride 0), so it contributes fmaf(0, 0, acc) exactly like the contract says.
+    const float* x = q4 < 3 ? A.in + (size_t)tile * VQ_XR_TILE + jj * VQ_XR_REC + q4 : A.zeros;
+    const int rstride = q4 < 3 ? 32 * VQ_XR_REC : 0, sbstride = q4 < 3 ? 16 * VQ_XR_REC : 0;
     f32x4* out4 = A.out ? (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
-    // per-lane input column offsets of the 8 outputs of a row: iw = ow + q4 - 1 (pad slot / halo -> 0)
-    int off[8];
-    bool ok[8];
-#pragma unroll
-    for (int ow = 0; ow < 8; ++ow) {
-        const int iw = ow + q4 - 1;
-        ok[ow] = (q4 < 3) && iw >= 0 && iw < 8;
-        off[ow] = (ok[ow] ? iw : 0) * 32;
-    }
     float ia[2][4], ib[2][4];  // MODE 1: GroupNorm(4,16) of y1, group = q4 (this lane's 4 couts)
     if (MODE == 1) {
 #pragma unroll
@@ -156,14 +167,14 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
     int4 e = steps[si];
     int4 en = steps[si + 1];
     // step entry: x = centre input row base (id*8+oh)*8, y = kd, w bits 8..10 = valid kh mask
-    float xn[3][8][2];
+    f32x4 xn[3][2][2];   // [kh][sub-tile][half row]
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-        const int rb = max(0, min(e.x + (kh - 1) * 8, 504)) * 32;
+        const int r = max(0, min((e.x >> 3) + (kh - 1), 63));
 #pragma unroll
-        for (int ow = 0; ow < 8; ++ow) {
-            xn[kh][ow][0] = x[rb + off[ow]];
-            xn[kh][ow][1] = x[rb + off[ow] + 16];
+        for (int sb = 0; sb < 2; ++sb) {
+            xn[kh][sb][0] = *(const f32x4u*)(x + r * rstride + sb * sbstride);
+            xn[kh][sb][1] = *(const f32x4u*)(x + r * rstride + sb * sbstride + 4);
         }
     }
     for (int row = g0; row < g1; ++row) {
@@ -172,22 +183,19 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
         for (int ow = 0; ow < 8; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0, 0, 0, 0};
         bool last;
         do {
-            float xc[3][8][2];
+            f32x4 xc[3][2][2];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int ow = 0; ow < 8; ++ow) {
-                    xc[kh][ow][0] = ok[ow] ? xn[kh][ow][0] : 0.0f;
-                    xc[kh][ow][1] = ok[ow] ? xn[kh][ow][1] : 0.0f;
-                }
+                for (int sb = 0; sb < 2; ++sb) xc[kh][sb][0] = xn[kh][sb][0], xc[kh][sb][1] = xn[kh][sb][1];   // first use: waits for this step's prefetch
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {  // unconditional, clamped: rows outside the leaf are never used (mask)
-                const int rb = max(0, min(en.x + (kh - 1) * 8, 504)) * 32;
+                const int r = max(0, min((en.x >> 3) + (kh - 1), 63));
 #pragma unroll
-                for (int ow = 0; ow < 8; ++ow) {
-                    xn[kh][ow][0] = x[rb + off[ow]];
-                    xn[kh][ow][1] = x[rb + off[ow] + 16];
+                for (int sb = 0; sb < 2; ++sb) {
+                    xn[kh][sb][0] = *(const f32x4u*)(x + r * rstride + sb * sbstride);
+                    xn[kh][sb][1] = *(const f32x4u*)(x + r * rstride + sb * sbstride + 4);
                 }
             }
             // e.y = kd selects the weight registers; a 3-way uniform select keeps the register index static
@@ -200,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     const float wv = kh == 0 ? w0 : (kh == 1 ? w1 : w2);
 #pragma unroll
                     for (int ow = 0; ow < 8; ++ow) {
-                        acc[ow][0] = mfma16(wv, xc[kh][ow][0], acc[ow][0]);
-                        acc[ow][1] = mfma16(wv, xc[kh][ow][1], acc[ow][1]);
+                        acc[ow][0] = mfma16(wv, xc[kh][0][ow >> 2][ow & 3], acc[ow][0]);
+                        acc[ow][1] = mfma16(wv, xc[kh][1][ow >> 2][ow & 3], acc[ow][1]);
                     }
                 }
             }
@@ -416,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
         for (int rw = 0; rw < NR; ++rw)
 #pragma unroll
             for (int ow = 0; ow < 8; ++ow) acc[rw][ow] = (f32x4){0, 0, 0, 0};
+        const int obase = e.z;  // (od*8 + oh0)*8 of this group, from the schedule (the table decides the order of the groups)
         bool last;
         do {
 #pragma unroll
@@ -461,7 +470,6 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
             ++si;
         } while (!last);
         // epilogue: the NR rows in order (positions ascending)
-        const int obase = grp * NR * 8;  // (od*8 + oh0)*8: groups tile the 64 rows in order
 #pragma unroll
         for (int rw = 0; rw < NR; ++rw) {
             f32x4 sk[RESID ? 8 : 1];

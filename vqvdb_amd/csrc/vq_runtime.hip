@@ -326,7 +326,7 @@ std::vector<int> steps_rows(int SI, int SO, int KS, int STRIDE, int PAD)
 std::vector<int> steps_rowgroups8(int NR)
 {
     std::vector<int> t;
-    for (int od = 0; od < 8; ++od)
+    for (int od = 0; od < 8; ++od) {
         for (int g = 0; g < 8 / NR; ++g) {
             const int oh0 = NR * g;
             const size_t first = t.size();
@@ -346,6 +346,7 @@ std::vector<int> steps_rowgroups8(int NR)
             t[first + 3] |= 1;
             t[t.size() - 1] |= 2;
         }
+    }
     return t;
 }
 
@@ -585,6 +586,7 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ed.w16", frag16g(edw->data, 32, 16, 64)) UP("ed.braw", edb)
     UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
     UP("cb", cb)
+    UP("zeros", std::vector<float>(64, 0.0f))   // operand of the first conv's K pad slot
     c->h_proj_w.assign(epw->data, epw->data + 128 * 32);
     c->h_proj_b.assign(epb->data, epb->data + 128);
     UP("tr.wproj", frag32(epw->data, 128, 32, 1)) UP("tr.bproj", dfrag32(epb->data, 128))
@@ -614,6 +616,7 @@ struct ActSpec {
     int C, NP;  // floats per leaf = C*NP ; C==0 -> per-leaf scalars, NP = count
 };
 const ActSpec kActs[] = {
+    {"xr", 1, 768},       // first-conv input, row layout with halo (pack_leaves_k): 64 rows x 12 floats per leaf
     {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
     {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},
     {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},
@@ -798,7 +801,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         // mid-size batches: the first conv twice (statistics, then recompute + normalise + store), like the one-wave-per-tile path,
         // instead of storing its raw output and normalising it in an elementwise pass (2 x 32 KiB per leaf less traffic)
         ConvArgs A{};
-        A.in = a["xt"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        A.in = a["xr"], A.zeros = w["zeros"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         const int psf = split_factor(g4, 8, 16, 1024);
         L.run("enc_conv_first_stats_s", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
@@ -808,7 +811,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         combine("enc_stats_a1", 8, 1.0 / 1024.0, a["st_b.mean"], a["st_b.rstd"]);
     } else {
         ConvArgs A{};
-        A.in = a["xt"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        A.in = a["xr"], A.zeros = w["zeros"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         combine("enc_stats_y1", 4, 1.0 / 2048.0, a["st_a.mean"], a["st_a.rstd"]);
@@ -898,12 +901,14 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
-    L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt, nt <= 128 ? 8 : 1), dim3(256), 0, s, d_leaves, a["xt"], n); });
+    // the position-major copy xt is only read by the training step (loss, first-conv weight gradients) and by debug fetches
+    float* xt = (c->training || c->full_training || c->debug) ? a["xt"] : nullptr;
+    L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt, nt <= 128 ? 8 : 1), dim3(256), 0, s, d_leaves, a["xr"], xt, n); });
     if (use_split(c, nt, false)) return encode_chunk_split(c, L, n, d_idx, s, d_latent);
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
-        A.in = a["xt"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
+        A.in = a["xr"], A.zeros = w["zeros"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
         L.run("enc_conv_first_stats", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
