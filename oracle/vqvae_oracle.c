@@ -31,8 +31,10 @@
  *       decoder stem, final conv : out = sum over valid taps ascending of P_tap, accumulated
  *                                  from 0 with plain adds, P_tap = fmaf chain over cin ("P8")
  *                                  from 0; then + bias.
- *   * GroupNorm statistics: fp64 accumulators, positions ascending then channels ascending;
- *     groups of 8 channels are the sum of two partials (low 4, high 4 channels);
+ *   * GroupNorm statistics: fp64 accumulators under the 16-BLOCK RULE (gn_stats below): the positions of a leaf form 16 equal
+ *     blocks (32 positions at 8^3, one row of 4 at 4^3); inside a block ONE sequential chain starting from zero, positions
+ *     ascending and, inside a position, the accumulator's channels ascending; the 16 block sums are then added in block order.
+ *     Groups of 8 channels are the sum of two such accumulators (low 4, high 4 channels), low + high.
  *     mean = S/N, var = fma(-mean,mean,Q/N) clamped at 0, rstd = 1/sqrt(var+1e-5) in fp64,
  *     both rounded to fp32.  Apply: a = rstd*gamma; b = fmaf(-mean,a,beta); y = fmaf(x,a,b).
  *   * residual: out = skip + (0.1f * (acc + bias))      (two roundings)

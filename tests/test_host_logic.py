@@ -207,3 +207,15 @@ def test_hostbench_index_file_writer_matches_numpy_framing(tmp_path):
     assert p.read_bytes() == want
     g = vqvdbfile.loads(p.read_bytes())[0]
     assert len(np.unique(g.origins, axis=0)) == 1000
+
+
+def test_integration_diff_compiles_against_the_reference_factory():
+    """INTEGRATION.md §2 applied to a temporary copy of the reference's real factory, compiled with the adapter and linked
+    against libvqvdb_hip.so (tools/prove_integration.py).  Needs /root/reference: build container only."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src/core"):
+        pytest.skip("reference tree not present (GPU box)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "prove_integration.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "integration proof: OK" in r.stdout, r.stdout + r.stderr
