@@ -136,7 +136,10 @@ int vqhip_multi_encode(vqhip_multi* multi, const float* leaves, int64_t n_leaves
 int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_leaves, float* leaves);
 
 /* Leaves processed per internal pass (default 65536).  Bounds the device workspace
- * (about 0.26 MB per leaf). */
+ * (about 0.1 MB per leaf for inference: three shared 32 KiB-per-leaf activation regions; 0.24 MB per leaf while
+ * debug mode or the training entry points keep every intermediate).  If the device has less free memory than the chunk
+ * needs (a GPU shared with a DCC application), the chunk is halved at the next call until it fits; results never depend
+ * on the chunk size. */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
 
 /* Small passes run the position-split kernels: each layer's output rows are spread over 4-16x more workgroups (the tiniest
@@ -149,9 +152,13 @@ int vqhip_set_small_batch_tiles(vqhip_codec* codec, int tiles);
 
 /* Allocates up front what calls of up to n_leaves leaves (capped at the chunk size) need: the device workspace,
  * the device I/O slots and the pinned staging buffers.  Optional — every entry point allocates lazily — but it
- * moves the one-time cost (hundreds of ms for a 65536-leaf chunk: ~17 GB of HBM, 0.5 GB pinned) out of the first
+ * moves the one-time cost (hundreds of ms for a 65536-leaf chunk: ~7 GB of HBM, 0.5 GB pinned) out of the first
  * cook, the way the reference backends pay model loading in IVQVAECodec::create. */
 int vqhip_reserve(vqhip_codec* codec, int64_t n_leaves);
+/* Bytes of device workspace the handle currently holds (activations + statistics; excludes weights and I/O slots), and the
+ * chunk size in effect (it may have been halved to fit a shared GPU's free memory). */
+int64_t vqhip_workspace_bytes(const vqhip_codec* codec);
+int64_t vqhip_chunk_leaves(const vqhip_codec* codec);
 
 /* ---- codebook training (extension; SURVEY.md §8 f-2, stage 1) ----------------------------------------------
  * The training-mode forward of VectorQuantizerEMA (python/VQVAE_v2.py:107-156) on the encoder's outputs: assign

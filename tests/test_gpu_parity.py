@@ -314,6 +314,28 @@ def test_config3_four_million_leaf_file_streamed_decode(codec, oracle, tmp_path)
           f"(read {st['read_s']:.3f} s, alloc {st['alloc_s']:.3f} s, scatter {st['copy_s']:.3f} s, waited for reader {st['io_wait_s']:.3f} s)")
 
 
+def test_workspace_is_compact_for_inference_and_full_for_debug(pack, oracle):
+    """<= 8 GB of workspace at the default 65 536-leaf chunk (three shared activation regions); debug mode
+    switches to the full layout (every intermediate at its own address) and back-to-back encode / decode on the shared regions
+    stay bit-exact."""
+    c = HipCodec(pack)
+    c.reserve(65536)
+    assert c.chunk_leaves() == 65536 and 0 < c.workspace_bytes() < 8e9, c.workspace_bytes()
+    compact = c.workspace_bytes()
+    leaves = synth.make_leaves(3000, seed=17)
+    idx = c.encode(leaves)
+    rec = c.decode(idx)
+    assert np.array_equal(idx, c.encode(leaves)) and np.array_equal(_bits(rec), _bits(c.decode(idx)))      # regions re-used across calls
+    assert np.array_equal(idx[:512], oracle.encode(leaves[:512], threads=16))
+    with pytest.raises(RuntimeError, match="compact inference workspace"):
+        c.debug_fetch("e_a1", 32, 16, 512)
+    c.debug_enable(True)
+    assert np.array_equal(c.encode(leaves), idx)
+    assert c.workspace_bytes() > 1.8 * compact
+    assert c.debug_fetch("e_a1", 32, 16, 512).shape == (32, 16, 512)
+    c.close()
+
+
 def test_leaf_pointer_entry_points(pack):
     """scattered per-leaf buffers in, scattered per-leaf buffers out, across chunk boundaries."""
     c = HipCodec(pack)

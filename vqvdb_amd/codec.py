@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
     "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
-    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state",
+    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -162,6 +162,10 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_apply_device.argtypes = [vp, vp, vp, cf, i64, cf, cf, cf, cf, cf, cf, vp]
     lib.vqhip_fulltrain_get_params.argtypes = [vp, vp]
     lib.vqhip_fulltrain_set_params.argtypes = [vp, vp]
+    lib.vqhip_workspace_bytes.argtypes = [vp]
+    lib.vqhip_workspace_bytes.restype = ctypes.c_int64
+    lib.vqhip_chunk_leaves.argtypes = [vp]
+    lib.vqhip_chunk_leaves.restype = ctypes.c_int64
     lib.vqhip_fulltrain_get_opt_state.argtypes = [vp, vp, vp]
     lib.vqhip_fulltrain_set_opt_state.argtypes = [vp, vp, vp]
     lib.vqhip_profile_enable.argtypes = [vp, ci]
@@ -183,7 +187,7 @@ def load_library() -> ctypes.CDLL:
         if getattr(lib, name).argtypes is None and name not in ("vqhip_version",):
             raise RuntimeError(f"codec.py: no argtypes declared for {name} (pointers would be truncated to 32 bits)")
         if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error",
-                        "vqhip_fulltrain_param_count"):
+                        "vqhip_fulltrain_param_count", "vqhip_workspace_bytes", "vqhip_chunk_leaves"):
             getattr(lib, name).restype = ci
     _lib = lib
     return lib
@@ -432,6 +436,12 @@ class HipCodec:
         out = np.empty((n, channels, positions), dtype=np.float32)
         self._check(self._lib.vqhip_debug_fetch(self._h, name.encode(), n, out.ctypes.data))
         return out
+
+    def workspace_bytes(self) -> int:
+        return int(self._lib.vqhip_workspace_bytes(self._h))
+
+    def chunk_leaves(self) -> int:
+        return int(self._lib.vqhip_chunk_leaves(self._h))
 
     def reserve(self, n: int):
         self._check(self._lib.vqhip_reserve(self._h, n))

@@ -86,6 +86,8 @@ struct vqhip_codec {
 
     // workspace
     int64_t ws_tiles = 0;
+    bool ws_full = false;    // workspace layout: full (every activation at its own address: debug, training) or compact (inference)
+    bool chunk_fitted = false;
     char* ws = nullptr;
     size_t ws_bytes = 0;
     std::map<std::string, float*> act;  // named activation buffers inside ws
@@ -611,46 +613,98 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
 }
 
 // ---------------- workspace ----------------
+// Inference keeps at most three large activations alive at a time (a conv reads its input and, for the second conv of a residual
+// block, the skip tensor, and writes its output), and encode and decode never overlap on one handle — so the COMPACT layout packs
+// every large activation of both directions into three regions of 32 KiB per leaf (0.1 MB per leaf, 6.8 GB for a 65 536-leaf
+// chunk instead of 15 GB).  Debug mode and the training step need every intermediate at its own address: FULL layout.
 struct ActSpec {
     const char* name;
-    int C, NP;  // floats per leaf = C*NP ; C==0 -> per-leaf scalars, NP = count
+    int C, NP;     // floats per leaf = C*NP ; C==0 -> per-leaf scalars, NP = count
+    int region;    // compact layout: -1 own buffer, 0..2 shared region, -2 not allocated (full layout only)
 };
 const ActSpec kActs[] = {
-    {"xr", 1, 768},       // first-conv input, row layout with halo (pack_leaves_k): 64 rows x 12 floats per leaf
-    {"xt", 1, 512},       {"e_y1", 16, 512},    {"e_a1", 16, 512},    {"e_y4", 16, 512},  {"e_a6", 16, 512},
-    {"e_x7", 32, 64},     {"e_y9", 32, 64},     {"e_x11", 32, 64},
-    {"d_ystem", 64, 64},  {"d_d2", 64, 64},     {"d_y4", 64, 64},     {"d_x6", 64, 64},
-    {"st_a.mean", 0, 8},  {"st_a.rstd", 0, 8},  {"st_b.mean", 0, 8},  {"st_b.rstd", 0, 8}, {"csum", 0, 64}, {"gate", 0, 64},
-    {"part_s", 0, 512},   {"part_q", 0, 512},   {"part_c", 0, 1024},   // per-block statistics partials of split launches (fp64 x 256, fp32 x 1024)
+    {"xr", 1, 768, -1},        // first-conv input, row layout with halo (pack_leaves_k): 64 rows x 12 floats per leaf
+    {"xt", 1, 512, -2},        // position-major copy of the input: training / debug only
+    // encode: xr -> a1 (R0) -> y4 (R1) -> a6 (R2, skip a1) -> x7 (R0) -> y9 (R1) -> x11 (R2, skip x7); y1 exists only in the
+    // small-batch path (written and consumed before y4) and in debug / training
+    {"e_y1", 16, 512, 1},      {"e_a1", 16, 512, 0},    {"e_y4", 16, 512, 1},    {"e_a6", 16, 512, 2},
+    {"e_x7", 32, 64, 0},       {"e_y9", 32, 64, 1},     {"e_x11", 32, 64, 2},
+    // decode: ystem (R0) -> d2 (R1) -> y4 (R2) -> x6 (R0, skip d2) -> voxels
+    {"d_ystem", 64, 64, 0},    {"d_d2", 64, 64, 1},     {"d_y4", 64, 64, 2},     {"d_x6", 64, 64, 0},
+    {"st_a.mean", 0, 8, -1},   {"st_a.rstd", 0, 8, -1}, {"st_b.mean", 0, 8, -1}, {"st_b.rstd", 0, 8, -1}, {"csum", 0, 64, -1}, {"gate", 0, 64, -1},
+    {"part_s", 0, 512, -1},    {"part_q", 0, 512, -1},  {"part_c", 0, 1024, -1},   // per-block statistics partials of split launches (fp64 x 256, fp32 x 1024)
 };
+constexpr int kRegions = 3;
+
+bool want_full_layout(const vqhip_codec* c) { return c->debug || c->training || c->full_training || c->keep_y1; }
+
+size_t workspace_bytes(int64_t tiles, bool full)
+{
+    auto sz = [&](size_t per_leaf_floats) { return ((per_leaf_floats * sizeof(float) * 32 * (size_t)tiles) + 255) / 256 * 256; };
+    size_t total = 0, region[kRegions] = {0, 0, 0};
+    for (const ActSpec& a : kActs) {
+        const size_t fl = a.C ? (size_t)a.C * a.NP : (size_t)a.NP;
+        if (full || a.region == -1) total += sz(fl);
+        else if (a.region >= 0) region[a.region] = std::max(region[a.region], sz(fl));
+    }
+    if (!full)
+        for (size_t r : region) total += r;
+    return total;
+}
 
 int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
 {
     const int64_t tiles = (n_leaves + 31) / 32;
-    if (tiles <= c->ws_tiles) return VQHIP_OK;
+    const bool full = want_full_layout(c);
+    if (tiles <= c->ws_tiles && (c->ws_full || !full)) return VQHIP_OK;   // a full layout also serves inference
+    const int64_t new_tiles = std::max(tiles, c->ws_tiles);
     if (c->ws) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipDeviceSynchronize());   // the workspace may be in use on a caller's stream
         HIPCHK(c, hipFree(c->ws));
         c->ws = nullptr;
         c->ws_tiles = 0;
     }
-    size_t total = 0;
-    for (const ActSpec& a : kActs) {
-        const size_t per_leaf = (a.C ? (size_t)a.C * a.NP : (size_t)a.NP) * sizeof(float);
-        total += ((per_leaf * 32 * tiles) + 255) / 256 * 256;
-    }
+    const size_t total = workspace_bytes(new_tiles, full);
     hipError_t e = hipMalloc(&c->ws, total);
-    if (e != hipSuccess) return fail(c, VQHIP_ERR_NOMEM, std::string("workspace hipMalloc failed: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(c, VQHIP_ERR_NOMEM, std::string("workspace hipMalloc of ") + std::to_string(total >> 20) + " MiB failed: " + hipGetErrorString(e));
     c->ws_bytes = total;
-    size_t off = 0;
-    for (const ActSpec& a : kActs) {
-        const size_t per_leaf = (a.C ? (size_t)a.C * a.NP : (size_t)a.NP) * sizeof(float);
-        c->act[a.name] = reinterpret_cast<float*>(c->ws + off);
-        c->act_shape[a.name] = {a.C, a.NP};
-        off += ((per_leaf * 32 * tiles) + 255) / 256 * 256;
+    auto sz = [&](size_t per_leaf_floats) { return ((per_leaf_floats * sizeof(float) * 32 * (size_t)new_tiles) + 255) / 256 * 256; };
+    size_t off = 0, region_off[kRegions] = {0, 0, 0};
+    if (!full) {   // the three shared regions first
+        size_t region[kRegions] = {0, 0, 0};
+        for (const ActSpec& a : kActs)
+            if (a.region >= 0) region[a.region] = std::max(region[a.region], sz((size_t)a.C * a.NP));
+        for (int r = 0; r < kRegions; ++r) region_off[r] = off, off += region[r];
     }
-    c->ws_tiles = tiles;
+    for (const ActSpec& a : kActs) {
+        const size_t fl = a.C ? (size_t)a.C * a.NP : (size_t)a.NP;
+        c->act_shape[a.name] = {a.C, a.NP};
+        if (full || a.region == -1) {
+            c->act[a.name] = reinterpret_cast<float*>(c->ws + off);
+            off += sz(fl);
+        } else if (a.region >= 0) {
+            c->act[a.name] = reinterpret_cast<float*>(c->ws + region_off[a.region]);
+        } else {
+            c->act[a.name] = nullptr;
+        }
+    }
+    c->ws_tiles = new_tiles;
+    c->ws_full = full;
     return VQHIP_OK;
+}
+
+// A shared GPU may not have room for the default chunk: halve the chunk until workspace + I/O slots fit into 80 % of the free
+// memory (never below 2048 leaves; results do not depend on the chunk size).
+void fit_chunk_to_free_memory(vqhip_codec* c)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    free_b += c->ws_bytes;   // what this handle already holds can be re-used
+    while (c->chunk > 2048) {
+        const size_t need = workspace_bytes((c->chunk + 31) / 32, want_full_layout(c)) + (size_t)c->chunk * (2 * 2048 + 2 * 64);
+        if (need <= free_b / 5 * 4) break;
+        c->chunk = (c->chunk / 2 + 31) / 32 * 32;
+    }
 }
 
 // ---------------- launches ----------------
@@ -1188,6 +1242,7 @@ using ConsumeFn = std::function<int(int64_t, int64_t, const void*)>;
 int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool want_stage, const ProduceFn& produce, const ConsumeFn& consume)
 {
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->chunk_fitted) fit_chunk_to_free_memory(c), c->chunk_fitted = true;
     step = std::min(step > 0 ? std::min(step, c->chunk) : c->chunk, n);
     int rc = ensure_tables(c);
     if (!rc) rc = ensure_io(c, step);
@@ -1419,6 +1474,7 @@ int vqhip_set_chunk_leaves(vqhip_codec* c, int64_t chunk)
     if (!c) return VQHIP_ERR_INVALID;
     if (chunk < 32 || chunk > (1 << 22)) return fail(c, VQHIP_ERR_INVALID, "chunk_leaves must be in [32, 4194304]");
     c->chunk = (chunk + 31) / 32 * 32;
+    c->chunk_fitted = false;   // re-checked against the free device memory at the next call
     return VQHIP_OK;
 }
 
@@ -1435,6 +1491,7 @@ int vqhip_reserve(vqhip_codec* c, int64_t n)
     if (!c) return VQHIP_ERR_INVALID;
     if (n < 1) return fail(c, VQHIP_ERR_INVALID, "reserve: n_leaves < 1");
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->chunk_fitted) fit_chunk_to_free_memory(c), c->chunk_fitted = true;
     const int64_t m = std::min(n, c->chunk);
     int rc = ensure_workspace(c, m);
     if (!rc) rc = ensure_io(c, m);
@@ -1442,11 +1499,16 @@ int vqhip_reserve(vqhip_codec* c, int64_t n)
     return rc;
 }
 
+int64_t vqhip_workspace_bytes(const vqhip_codec* c) { return c ? (int64_t)c->ws_bytes : -1; }
+
+int64_t vqhip_chunk_leaves(const vqhip_codec* c) { return c ? c->chunk : -1; }
+
 int vqhip_encode_device(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_idx, void* stream)
 {
     if (!c) return VQHIP_ERR_INVALID;
     if (!d_leaves || !d_idx || n < 1) return fail(c, VQHIP_ERR_INVALID, "encode: null pointer or n_leaves < 1");
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->chunk_fitted) fit_chunk_to_free_memory(c), c->chunk_fitted = true;
     if (int trc = ensure_tables(c)) return trc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     for (int64_t o = 0; o < n; o += c->chunk) {
@@ -1462,6 +1524,7 @@ int vqhip_decode_device(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* 
     if (!c) return VQHIP_ERR_INVALID;
     if (!d_idx || !d_out || n < 1) return fail(c, VQHIP_ERR_INVALID, "decode: null pointer or n_leaves < 1");
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->chunk_fitted) fit_chunk_to_free_memory(c), c->chunk_fitted = true;
     if (int trc = ensure_tables(c)) return trc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     for (int64_t o = 0; o < n; o += c->chunk) {
@@ -1981,6 +2044,10 @@ int vqhip_debug_fetch(vqhip_codec* c, const char* name, int64_t n, float* out)
     if (it == c->act.end()) return fail(c, VQHIP_ERR_INVALID, std::string("debug_fetch: unknown activation '") + name + "'");
     const int C = c->act_shape[name].first, NP = c->act_shape[name].second;
     if ((C != 1 && C < 4) || n > std::max(c->ws_tiles, c->ft_tiles) * 32) return fail(c, VQHIP_ERR_INVALID, "debug_fetch: not a tile activation or n too large");
+    for (const ActSpec& a : kActs)   // compact (inference) layout: large activations share three regions and overwrite each other
+        if (!c->ws_full && a.region != -1 && std::strcmp(a.name, name) == 0)
+            return fail(c, VQHIP_ERR_INVALID, std::string("debug_fetch: '") + name + "' is not kept in the compact inference workspace; call vqhip_debug_enable(1) before the pass");
+    if (!it->second) return fail(c, VQHIP_ERR_INVALID, std::string("debug_fetch: '") + name + "' is not allocated");
     if (C == 1) {  // [tile][NP][32]
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipDeviceSynchronize());
