@@ -153,6 +153,23 @@ def host_legs(args):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+class _RehearsalCodec:
+    """CPU stand-in used ONLY by tests/test_sharding_gloo.py (VQ_BENCH_CPU_REHEARSAL=1) to exercise this file's N > 1 protocol —
+    process group, barriers, max-over-ranks timing, per-rank gathers, the JSON shape — on a box without a GPU.  It computes
+    nothing; a line produced this way says so in `data` and is not a measurement."""
+
+    def set_chunk_leaves(self, n): pass
+    def encode_device(self, *a): time.sleep(2e-4)
+    def decode_device(self, *a): time.sleep(2e-4)
+    def profile_enable(self, on): pass
+
+    def profile_read(self):
+        return [dict(name=n, launches=4, total_ms=4 * ms, flops_per_leaf=2 * f, eff_flops_per_leaf=f, leaves=4 * BATCH)
+                for n, ms, f in (("rehearsal_kernel_a", 3.0, 5.0e6), ("rehearsal_kernel_b", 1.0, 1.0e6))]
+
+    def close(self): pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,12 +195,19 @@ def main():
     # Rehearsal of the N > 1 code path on a box with ONE GPU (tests/tools only): every rank uses cuda:0 and the process
     # group runs on gloo (RCCL refuses two ranks on one device).  The numbers of such a run are meaningless.
     rehearsal = os.environ.get("VQ_BENCH_SINGLE_GPU_REHEARSAL") == "1"
+    # ... and on a box with NO GPU (CPU tests of the N > 1 protocol only): a stand-in codec that computes nothing, gloo, CPU tensors
+    cpu_rehearsal = os.environ.get("VQ_BENCH_CPU_REHEARSAL") == "1"
+    if cpu_rehearsal:
+        rehearsal = True
+        args.no_cpu_baseline = args.no_train = args.no_host_path = True
+        torch.cuda.synchronize = lambda *a, **k: None
     dev_index = 0 if rehearsal else local
     dist = world > 1 or os.environ.get("VQ_BENCH_FORCE_DIST") == "1"   # the latter exercises the RCCL path with one rank
     if not dist and args.gpus != 1:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    device = torch.device("cuda", dev_index)
-    torch.cuda.set_device(device)
+    device = torch.device("cpu") if cpu_rehearsal else torch.device("cuda", dev_index)
+    if not cpu_rehearsal:
+        torch.cuda.set_device(device)
     # one rank = one GPU = its own slice of the host's cores (NUMA node of the GPU when the topology is readable): the host-side
     # copy threads of N ranks must not pile onto the same cores
     affinity = None
@@ -199,21 +223,23 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", device_id=device)
     # what the collective library really saw: an all-reduce of ones over the group, and each rank's device
-    backend, ranks_seen, devices_seen = None, 1, [torch.cuda.get_device_name(device)]
+    dev_name = "cpu (rehearsal)" if cpu_rehearsal else torch.cuda.get_device_name(device)
+    dev_props = None if cpu_rehearsal else torch.cuda.get_device_properties(device)
+    backend, ranks_seen, devices_seen = None, 1, [dev_name]
     if dist:
         backend = torch.distributed.get_backend()
         one = torch.ones(1, device=device if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(one)
         ranks_seen = int(one.item())
         objs = [None] * torch.distributed.get_world_size()
-        torch.distributed.all_gather_object(objs, {"rank": rank, "local_rank": local, "device": dev_index, "name": torch.cuda.get_device_name(device),
-                                                   "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+        torch.distributed.all_gather_object(objs, {"rank": rank, "local_rank": local, "device": dev_index, "name": dev_name,
+                                                   "pci_bus_id": getattr(dev_props, "pci_bus_id", None),
                                                    "cpus": (affinity or {}).get("cpus_bound")})
         devices_seen = objs
         assert ranks_seen == world == torch.distributed.get_world_size(), (ranks_seen, world)
 
     W = synth.make_weights(0)
-    codec = HipCodec(weightpack.dumps(W), device_id=dev_index)
+    codec = _RehearsalCodec() if cpu_rehearsal else HipCodec(weightpack.dumps(W), device_id=dev_index)
     codec.set_chunk_leaves(BATCH)
 
     # N > 1: every rank covers at least its configs[3] shard (8 Mi leaves = 128 batches)
@@ -221,13 +247,14 @@ def main():
 
     # synthetic leaves, uniform [0,1) (training data is [0,1]-normalised), resident in HBM; each
     # rank gets its own shard (different seed) -> no data-path collective.
-    nb = min(steps, 16)
+    nb = 1 if cpu_rehearsal else min(steps, 16)
+    rows = 64 if cpu_rehearsal else BATCH                     # the stand-in codec touches no memory
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
-    leaves = [torch.rand(BATCH, 512, device=device, dtype=torch.float32, generator=gen) for _ in range(nb)]
-    idx = [torch.empty(BATCH, 64, device=device, dtype=torch.uint8) for _ in range(nb)]
-    rec = torch.empty(BATCH, 512, device=device, dtype=torch.float32)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    leaves = [torch.rand(rows, 512, device=device, dtype=torch.float32, generator=gen) for _ in range(nb)]
+    idx = [torch.empty(rows, 64, device=device, dtype=torch.uint8) for _ in range(nb)]
+    rec = torch.empty(rows, 512, device=device, dtype=torch.float32)
+    stream = 0 if cpu_rehearsal else torch.cuda.current_stream(device).cuda_stream
 
     def enc(s):
         codec.encode_device(leaves[s % nb].data_ptr(), BATCH, idx[s % nb].data_ptr(), stream)
@@ -257,7 +284,7 @@ def main():
     # Small-batch latency (position-split kernels): what the SOP's per-batch calls see (default 64, max 1024 encode / 8192
     # decode leaves, SOP_VQVDB_Encoder.cpp:33-38).  Device-resident, rank 0 only.
     small = None
-    if rank == 0:
+    if rank == 0 and not cpu_rehearsal:
         small = {"note": "ms per call on the device at SOP-sized batches (position-split path); not the headline value"}
         for nsm in (64, 1024, 8192):
             for _ in range(3):
@@ -351,7 +378,7 @@ def main():
             "metric": "8^3 leaves/s encode+quantize (decode reported under 'decode')",
             "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(t_enc / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not cpu_rehearsal else "REHEARSAL on CPU with a stand-in codec: protocol test only, not a measurement",
             "config": {"workload": (f"BASELINE configs[1]: 1xMI355X, 1M synthetic leaves (16 x 65536-leaf batches, cycled for {steps} steps), fp32 encoder+quantizer, K=256 D=128" if world == 1 else
                                     f"BASELINE configs[3]: {world}xMI355X encode, leaves sharded across GPUs, {steps * BATCH} leaves per GPU "
                                     f"(>= the 8 Mi-leaf shard of the 64M-leaf job; 65536-leaf batches), fp32 encoder+quantizer, K=256 D=128"),

@@ -127,10 +127,15 @@ int vqhip_compress_file(vqhip_codec* codec, const char* path, const vqhip_grid_s
 /* In-process multi-GPU front end (extension): one codec and one host thread per listed
  * device, device g of G takes the contiguous leaf range [g*ceil(n/G), min(n,(g+1)*ceil(n/G))) of every call
  * and writes to the same offsets of the caller's buffer.  Weights are replicated; there is no collective.
+ * The host threads are persistent (created here, asleep between calls); each is bound to the cores of its GPU's NUMA
+ * node when /sys exposes it (pinned staging is then allocated node-local), and all devices together fan out to at
+ * most min(cores, 64) copy threads (override per thread with the environment variable VQHIP_COPY_THREADS).
  * (Process-per-GPU callers use one plain codec per rank instead: bench.py, vqvdb_amd/sharding.py.) */
 typedef struct vqhip_multi vqhip_multi;
 int vqhip_multi_create(const char* pack_path, const void* pack_bytes, size_t pack_size, const int* device_ids, int n_devices, vqhip_multi** out);
 void vqhip_multi_destroy(vqhip_multi* multi);
+/* What worker `index` (0 .. n_devices-1) was bound to: numa_node = -1 / cpus_bound = 0 if the topology is not exposed. */
+int vqhip_multi_worker_info(const vqhip_multi* multi, int index, int* device_id, int* numa_node, int* cpus_bound);
 const char* vqhip_multi_last_error(const vqhip_multi* multi);
 int vqhip_multi_encode(vqhip_multi* multi, const float* leaves, int64_t n_leaves, uint8_t* indices);
 int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_leaves, float* leaves);

@@ -364,6 +364,14 @@ def test_in_process_multi_device_sharding(codec, pack):
     assert np.array_equal(idx, codec.encode(leaves))
     assert np.array_equal(_bits(m.decode(idx)), _bits(codec.decode(idx)))
     assert np.array_equal(m.encode(leaves[:2]), idx[:2])       # fewer leaves than devices
+    # the per-device host threads are persistent: many calls, alternating directions and sizes, re-use them
+    big = synth.make_leaves(9000, seed=14)
+    want = codec.encode(big)
+    for _ in range(3):
+        assert np.array_equal(m.encode(big), want)
+        assert np.array_equal(_bits(m.decode(want[:777])), _bits(codec.decode(want[:777])))
+    info = m.worker_info()
+    assert [d for d, _, _ in info] == [0, 0, 0] and all(nn >= -1 and cb >= 0 for _, nn, cb in info)
     with pytest.raises(RuntimeError, match="device_id out of range"):
         HipMultiCodec(pack, [0, 99])
     m.close()

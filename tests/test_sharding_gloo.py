@@ -70,3 +70,32 @@ def test_two_rank_gloo_sharded_roundtrip():
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=10) == (True, True)
+
+
+def test_bench_n_gt_1_protocol_and_json_shape_without_a_gpu():
+    """bench.py's N > 1 path launched exactly like the driver launches it (torch.distributed.run, one process per rank) with the
+    CPU stand-in codec (VQ_BENCH_CPU_REHEARSAL=1, gloo): process group, ranks_seen via an all-reduce, per-rank gathers,
+    max-over-ranks timing, the configs[3] workload rule (>= 128 batches per rank), ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, VQ_BENCH_CPU_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "collective_backend", "ranks_seen", "devices_seen", "per_rank"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["collective_backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["steps"] == 128 and d["config"]["steps_requested"] == 5 and d["config"]["leaves_per_gpu"] == 128 * 65536
+    assert "configs[3]" in d["config"]["workload"] and "REHEARSAL" in d["data"]
+    assert [o["rank"] for o in d["devices_seen"]] == [0, 1]
+    assert len(d["per_rank"]["encode_leaves_per_s"]) == 2 and len(d["per_rank"]["decode_leaves_per_s"]) == 2
+    # value = all ranks' leaves over the slowest rank's time: never more than the sum of the per-rank rates
+    assert 0 < d["value"] <= sum(d["per_rank"]["encode_leaves_per_s"]) * 1.001
+    assert abs(d["ms_per_step"] * d["steps"] * 1e-3 * d["value"] - 2 * 128 * 65536) < 1e-3 * 2 * 128 * 65536
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["unit"] == "TFLOP/s" and d["roofline"]["bound"] == "mfma"
+    assert d["host_path"] and "skipped" in d["host_path"]

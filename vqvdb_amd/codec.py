@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
     "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
-    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves",
+    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -162,6 +162,7 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_apply_device.argtypes = [vp, vp, vp, cf, i64, cf, cf, cf, cf, cf, cf, vp]
     lib.vqhip_fulltrain_get_params.argtypes = [vp, vp]
     lib.vqhip_fulltrain_set_params.argtypes = [vp, vp]
+    lib.vqhip_multi_worker_info.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.vqhip_workspace_bytes.argtypes = [vp]
     lib.vqhip_workspace_bytes.restype = ctypes.c_int64
     lib.vqhip_chunk_leaves.argtypes = [vp]
@@ -477,6 +478,7 @@ class HipMultiCodec:
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        self._n = len(device_ids)
         if isinstance(pack, (bytes, bytearray, memoryview)):
             self._pack = bytes(pack)
             rc = self._lib.vqhip_multi_create(None, self._pack, len(self._pack), ids, len(device_ids), ctypes.byref(self._h))
@@ -495,6 +497,15 @@ class HipMultiCodec:
             self._h = ctypes.c_void_p()
 
     __del__ = close
+
+    def worker_info(self) -> list:
+        """Per device worker: (device_id, numa_node or -1, cores bound or 0)."""
+        out = []
+        for k in range(self._n):
+            d, nn, cb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            self._check(self._lib.vqhip_multi_worker_info(self._h, k, ctypes.byref(d), ctypes.byref(nn), ctypes.byref(cb)))
+            out.append((d.value, nn.value, cb.value))
+        return out
 
     def encode(self, leaves: np.ndarray) -> np.ndarray:
         leaves = np.ascontiguousarray(leaves, dtype=np.float32).reshape(-1, LEAF_VOXELS)

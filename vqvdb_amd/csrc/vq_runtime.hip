@@ -5,8 +5,12 @@
 // pinned staging buffers for the host-pointer entry points.  No PyTorch / ONNX / CPU
 // fallback: if HIP is unavailable every entry point fails with VQHIP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1169,12 +1173,26 @@ int ensure_stage(vqhip_codec* c, int64_t n)
     return VQHIP_OK;
 }
 
+// Cap on the copy threads one calling thread may fan out to (host_parallel_for).  Default 16; the in-process multi-device front
+// end lowers it per device worker so that G devices never run more than min(cores, 64) copy threads together; the environment
+// variable VQHIP_COPY_THREADS overrides both.
+thread_local int g_copy_threads_cap = 16;
+
+int copy_threads_cap()
+{
+    static const int env = [] {
+        const char* e = std::getenv("VQHIP_COPY_THREADS");
+        return e ? std::max(1, std::atoi(e)) : 0;
+    }();
+    return env ? env : g_copy_threads_cap;
+}
+
 // parallel-for over [0,n) on host threads (the library's stand-in for the orchestrator's tbb::parallel_for)
 template <typename F>
 void host_parallel_for(int64_t n, F&& f, int64_t grain = 2048)
 {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw / 2, (int64_t)16, n / grain}));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw / 2, (int64_t)copy_threads_cap(), n / grain}));
     if (nt <= 1) {
         f(0, n);
         return;
@@ -1925,10 +1943,92 @@ int vqhip_train_commit(vqhip_codec* c)
 }
 
 // ---- in-process multi-GPU front end: one codec + one host thread per device, contiguous leaf ranges ----
+// One persistent host thread per device: it owns the device's handle for the lifetime of the front end (hipSetDevice once, pinned
+// staging allocated from this thread, i.e. on the memory node of the cores it is bound to), sleeps on a condition variable between
+// calls and runs one leaf range per call.  The thread is bound to the cores of its GPU's NUMA node when /sys exposes it; the
+// copy threads a call fans out to inherit that mask.
+struct MultiWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, done = true, quit = false;
+    bool is_encode = false;
+    const void* in = nullptr;
+    void* out = nullptr;
+    int64_t n = 0;
+    int rc = VQHIP_OK;
+    int numa_node = -1, cpus_bound = 0;
+};
+
 struct vqhip_multi {
     std::vector<vqhip_codec*> dev;
+    std::vector<std::unique_ptr<MultiWorker>> workers;
     std::string err;
 };
+
+// cores of the NUMA node the device hangs off (empty if unknown)
+static std::vector<int> device_numa_cpus(int device, int* node_out)
+{
+    std::vector<int> cpus;
+    char bus[64] = {0};
+    *node_out = -1;
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) return cpus;
+    for (char* p = bus; *p; ++p) *p = (char)std::tolower(*p);
+    std::ifstream fn(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
+    int node = -1;
+    if (!(fn >> node) || node < 0) return cpus;
+    *node_out = node;
+    std::ifstream fl("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    std::string list;
+    if (!std::getline(fl, list)) return cpus;
+    size_t pos = 0;
+    while (pos < list.size()) {
+        size_t end = list.find(',', pos);
+        if (end == std::string::npos) end = list.size();
+        const std::string part = list.substr(pos, end - pos);
+        const size_t dash = part.find('-');
+        try {
+            const int lo = std::stoi(part.substr(0, dash)), hi = dash == std::string::npos ? lo : std::stoi(part.substr(dash + 1));
+            for (int cpu = lo; cpu <= hi; ++cpu) cpus.push_back(cpu);
+        } catch (...) {
+            return {};
+        }
+        pos = end + 1;
+    }
+    return cpus;
+}
+
+static void multi_worker_main(vqhip_multi* m, int g, int copy_cap)
+{
+    MultiWorker& w = *m->workers[g];
+    g_copy_threads_cap = copy_cap;
+    hipSetDevice(m->dev[g]->device);
+    {   // NUMA-local: restrict this thread (and the copy threads it spawns) to the device's node, within the process's mask
+        int node = -1;
+        const std::vector<int> cpus = device_numa_cpus(m->dev[g]->device, &node);
+        cpu_set_t cur, want;
+        CPU_ZERO(&want);
+        if (!cpus.empty() && sched_getaffinity(0, sizeof(cur), &cur) == 0) {
+            int cnt = 0;
+            for (int cpu : cpus)
+                if (cpu < CPU_SETSIZE && CPU_ISSET(cpu, &cur)) CPU_SET(cpu, &want), ++cnt;
+            if (cnt > 0 && sched_setaffinity(0, sizeof(want), &want) == 0) w.numa_node = node, w.cpus_bound = cnt;
+        }
+    }
+    std::unique_lock<std::mutex> lk(w.mu);
+    for (;;) {
+        w.cv.wait(lk, [&] { return w.has_job || w.quit; });
+        if (w.quit) return;
+        w.has_job = false;
+        lk.unlock();
+        const int rc = w.is_encode ? vqhip_encode(m->dev[g], static_cast<const float*>(w.in), w.n, static_cast<uint8_t*>(w.out))
+                                   : vqhip_decode(m->dev[g], static_cast<const uint8_t*>(w.in), w.n, static_cast<float*>(w.out));
+        lk.lock();
+        w.rc = rc;
+        w.done = true;
+        w.cv.notify_all();
+    }
+}
 
 int vqhip_multi_create(const char* pack_path, const void* pack_bytes, size_t pack_size, const int* device_ids, int n_devices, vqhip_multi** out)
 {
@@ -1946,6 +2046,12 @@ int vqhip_multi_create(const char* pack_path, const void* pack_bytes, size_t pac
         }
         m->dev.push_back(c);
     }
+    // all devices together never run more than min(cores, 64) copy threads: 8 GPUs x 16 threads each would oversubscribe the
+    // memory controllers long before they help a 57 GB/s PCIe link
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int cap = std::max(2, std::min(16, std::min(hw, 64) / n_devices));
+    for (int g = 0; g < n_devices; ++g) m->workers.emplace_back(new MultiWorker());
+    for (int g = 0; g < n_devices; ++g) m->workers[g]->th = std::thread(multi_worker_main, m, g, cap);
     *out = m;
     return VQHIP_OK;
 }
@@ -1953,11 +2059,28 @@ int vqhip_multi_create(const char* pack_path, const void* pack_bytes, size_t pac
 void vqhip_multi_destroy(vqhip_multi* m)
 {
     if (!m) return;
+    for (auto& w : m->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
     for (vqhip_codec* d : m->dev) vqhip_destroy(d);
     delete m;
 }
 
 const char* vqhip_multi_last_error(const vqhip_multi* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+int vqhip_multi_worker_info(const vqhip_multi* m, int index, int* device_id, int* numa_node, int* cpus_bound)
+{
+    if (!m || index < 0 || index >= (int)m->workers.size()) return VQHIP_ERR_INVALID;
+    if (device_id) *device_id = m->dev[index]->device;
+    if (numa_node) *numa_node = m->workers[index]->numa_node;
+    if (cpus_bound) *cpus_bound = m->workers[index]->cpus_bound;
+    return VQHIP_OK;
+}
 
 // rank g of G takes leaves [g*ceil(n/G), min(n,(g+1)*ceil(n/G))); results land at the same
 // offsets of the caller's buffer, so leaf order is preserved and there is no collective.
@@ -1970,22 +2093,35 @@ static int multi_run(vqhip_multi* m, bool is_encode, const void* in, void* out, 
     }
     const int G = (int)m->dev.size();
     const int64_t per = (n + G - 1) / G;
-    std::vector<int> rcs(G, VQHIP_OK);
-    std::vector<std::thread> th;
+    std::vector<char> posted(G, 0);
     for (int g = 0; g < G; ++g) {
         const int64_t lo = std::min(n, g * per), hi = std::min(n, lo + per);
         if (hi == lo) continue;
-        th.emplace_back([=, &rcs] {
-            rcs[g] = is_encode ? vqhip_encode(m->dev[g], static_cast<const float*>(in) + lo * 512, hi - lo, static_cast<uint8_t*>(out) + lo * 64)
-                               : vqhip_decode(m->dev[g], static_cast<const uint8_t*>(in) + lo * 64, hi - lo, static_cast<float*>(out) + lo * 512);
-        });
-    }
-    for (auto& t : th) t.join();
-    for (int g = 0; g < G; ++g)
-        if (rcs[g] != VQHIP_OK) {
-            m->err = "device " + std::to_string(m->dev[g]->device) + ": " + m->dev[g]->err;
-            return rcs[g];
+        MultiWorker& w = *m->workers[g];
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.is_encode = is_encode;
+            w.in = is_encode ? static_cast<const void*>(static_cast<const float*>(in) + lo * 512) : static_cast<const void*>(static_cast<const uint8_t*>(in) + lo * 64);
+            w.out = is_encode ? static_cast<void*>(static_cast<uint8_t*>(out) + lo * 64) : static_cast<void*>(static_cast<float*>(out) + lo * 512);
+            w.n = hi - lo;
+            w.done = false;
+            w.has_job = true;
         }
+        w.cv.notify_all();
+        posted[g] = 1;
+    }
+    int first_bad = -1, rc_bad = VQHIP_OK;
+    for (int g = 0; g < G; ++g) {
+        if (!posted[g]) continue;
+        MultiWorker& w = *m->workers[g];
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.done; });
+        if (w.rc != VQHIP_OK && first_bad < 0) first_bad = g, rc_bad = w.rc;
+    }
+    if (first_bad >= 0) {
+        m->err = "device " + std::to_string(m->dev[first_bad]->device) + ": " + m->dev[first_bad]->err;
+        return rc_bad;
+    }
     return VQHIP_OK;
 }
 
