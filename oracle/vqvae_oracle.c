@@ -34,6 +34,8 @@
  *   * GroupNorm statistics: fp64 accumulators under the 16-BLOCK RULE (gn_stats below): the positions of a leaf form 16 equal
  *     blocks (32 positions at 8^3, one row of 4 at 4^3); inside a block ONE sequential chain starting from zero, positions
  *     ascending and, inside a position, the accumulator's channels ascending; the 16 block sums are then added in block order.
+ *     One tensor uses 64 blocks (one W-row of 8 positions each, added row-major: see gn_stats_nb) instead: the output of the
+ *     16-channel residual block's first conv at 8^3 (statistics for its gn2).
  *     Groups of 8 channels are the sum of two such accumulators (low 4, high 4 channels), low + high.
  *     mean = S/N, var = fma(-mean,mean,Q/N) clamped at 0, rstd = 1/sqrt(var+1e-5) in fp64,
  *     both rounded to fp32.  Apply: a = rstd*gamma; b = fmaf(-mean,a,beta); y = fmaf(x,a,b).
@@ -374,7 +376,7 @@ static void conv_final(const float* in /*[32][512][LT]*/, float* out /*[512][LT]
 }
 
 /* ---- GroupNorm ---- */
-static void gn_stats(const float* x, int C, int G, int NP, float* mean /*[G][LT]*/, float* rstd)
+static void gn_stats_nb(const float* x, int C, int G, int NP, int NBLK, float* mean /*[G][LT]*/, float* rstd)
 {
     const int cpg = C / G;
     const int nparts = (cpg == 8) ? 2 : 1, cpp = cpg / nparts;
@@ -383,25 +385,38 @@ static void gn_stats(const float* x, int C, int G, int NP, float* mean /*[G][LT]
         double S[LT], Q[LT];
         for (int l = 0; l < LT; ++l) S[l] = Q[l] = 0.0;
         for (int part = 0; part < nparts; ++part) {
-            /* contract: the NP positions form 16 equal blocks; each block is one sequential chain (positions
-               ascending, channels ascending) starting from zero, and the block sums are added in block order.  A launch that
-               splits a layer over up to 16 position ranges can therefore fuse the statistics (per-block partials). */
+            /* contract: the NP positions form NBLK equal blocks; each block is one sequential chain (positions
+               ascending, channels ascending) starting from zero.
+               NBLK = 16 (everywhere but one tensor): the block sums are added in block order — a launch that splits a layer over
+               up to 16 position ranges can fuse the statistics as per-block partials.
+               NBLK = 64 (output of the 16-channel residual block's first conv at 8^3): a block is one W-row of 8 positions,
+               block (od, oh) = od*8 + oh, and the blocks are added ROW-MAJOR: for oh = 0..7 { t = sum over od = 0..7 of
+               block(od, oh), from zero, od ascending }, the eight t added in oh order.  That is the order of the LDS-plane
+               kernel conv8_lds_k, where a wave owns row oh of every plane of its half tile. */
             double s[LT], q[LT];
             for (int l = 0; l < LT; ++l) s[l] = q[l] = 0.0;
-            const int BP = NP / 16;
-            for (int b = 0; b < 16; ++b) {
-                double sb[LT], qb[LT];
-                for (int l = 0; l < LT; ++l) sb[l] = qb[l] = 0.0;
-                for (int p = b * BP; p < (b + 1) * BP; ++p)
-                    for (int cc = 0; cc < cpp; ++cc) {
-                        const float* v = x + ((size_t)(g * cpg + part * cpp + cc) * NP + p) * LT;
-                        for (int l = 0; l < LT; ++l) {
-                            const double d = (double)v[l];
-                            sb[l] += d;
-                            qb[l] = fma(d, d, qb[l]);
+            const int BP = NP / NBLK;
+            const int outer = NBLK == 64 ? 8 : 1, inner = NBLK / outer;
+            for (int o = 0; o < outer; ++o) {
+                double ts[LT], tq[LT];
+                for (int l = 0; l < LT; ++l) ts[l] = tq[l] = 0.0;
+                for (int i = 0; i < inner; ++i) {
+                    const int b = NBLK == 64 ? i * 8 + o : i;     /* 64: od = i, oh = o */
+                    double sb[LT], qb[LT];
+                    for (int l = 0; l < LT; ++l) sb[l] = qb[l] = 0.0;
+                    for (int p = b * BP; p < (b + 1) * BP; ++p)
+                        for (int cc = 0; cc < cpp; ++cc) {
+                            const float* v = x + ((size_t)(g * cpg + part * cpp + cc) * NP + p) * LT;
+                            for (int l = 0; l < LT; ++l) {
+                                const double d = (double)v[l];
+                                sb[l] += d;
+                                qb[l] = fma(d, d, qb[l]);
+                            }
                         }
-                    }
-                for (int l = 0; l < LT; ++l) { s[l] += sb[l]; q[l] += qb[l]; }
+                    for (int l = 0; l < LT; ++l) { ts[l] += sb[l]; tq[l] += qb[l]; }
+                }
+                if (outer == 1) for (int l = 0; l < LT; ++l) { s[l] = ts[l]; q[l] = tq[l]; }
+                else for (int l = 0; l < LT; ++l) { s[l] += ts[l]; q[l] += tq[l]; }
             }
             if (part == 0) for (int l = 0; l < LT; ++l) { S[l] = s[l]; Q[l] = q[l]; }
             else for (int l = 0; l < LT; ++l) { S[l] = S[l] + s[l]; Q[l] = Q[l] + q[l]; }
@@ -415,6 +430,8 @@ static void gn_stats(const float* x, int C, int G, int NP, float* mean /*[G][LT]
         }
     }
 }
+
+static void gn_stats(const float* x, int C, int G, int NP, float* mean, float* rstd) { gn_stats_nb(x, C, G, NP, 16, mean, rstd); }
 
 static void gn_relu(const float* x, float* y, int C, int G, int NP, const float* mean, const float* rstd,
                     const float* gamma, const float* beta)
@@ -448,7 +465,7 @@ static void res_block(const float* x, float* out, float* t0, float* t1, int C, i
     gn_relu(x, t0, C, 8, NP, mean, rstd, W[base + 0], W[base + 1]);
     conv3d(t0, t1, W[base + 2], W[base + 3], C, C, S, S, 3, 1, 1, kord);
     if (y_mid_dump) memcpy(y_mid_dump, t1, sizeof(float) * C * NP * LT);
-    gn_stats(t1, C, 8, NP, mean, rstd);
+    gn_stats_nb(t1, C, 8, NP, (C == 16 && S == 8) ? 64 : 16, mean, rstd);   /* row blocks for the 8^3 block's conv1 output */
     gn_relu(t1, t0, C, 8, NP, mean, rstd, W[base + 4], W[base + 5]);
     /* conv2 without bias add, then out = x + 0.1*(acc + bias) */
     static const float zero_bias[256] = {0};

@@ -493,22 +493,14 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                     st[1].add(v.w);
                 }
             }
-        }
-        if (STATS) {   // NR rows closed: 16 statistics blocks of 32 positions per leaf
-            static_assert(!STATS || NR == 4, "statistics blocks are 4 rows");
-            st[0].fold_store(A.part_s, A.part_q, part_index(tile, grp, 2 * q4 + 0, jj));   // slot = GroupNorm(8,16) group
-            st[1].fold_store(A.part_s, A.part_q, part_index(tile, grp, 2 * q4 + 1, jj));
-        }
-    }
-    if (STATS && !A.part_s) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float m, r;
-            gn_finish(st[k].s, st[k].q, 1.0 / 1024.0, m, r);
-            A.out_mean[((size_t)tile * 8 + 2 * q4 + k) * 32 + jj] = m;
-            A.out_rstd[((size_t)tile * 8 + 2 * q4 + k) * 32 + jj] = r;
+            if (STATS) {   // one output row closed = one statistics block of this tensor (64 row blocks per leaf)
+                st[0].fold_store(A.part_s, A.part_q, part_index_rows(tile, (obase >> 3) + rw, 2 * q4 + 0, jj));   // slot = GroupNorm(8,16) group
+                st[1].fold_store(A.part_s, A.part_q, part_index_rows(tile, (obase >> 3) + rw, 2 * q4 + 1, jj));
+            }
         }
     }
+    // (the row blocks of this tensor are added row-major, not in the order a wave produces them: gn_combine_k<false, true> finishes;
+    // every STATS launch passes the partial buffers)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1363,6 +1355,38 @@ __global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __rest
     }
 }
 
+// ... and for the tensor whose statistics blocks are its 64 output rows, added row-major (conv1 output of the 16-channel residual
+// block): wave = channel quads (2w, 2w+1), GroupNorm(8,16): 2 channels per group.
+__global__ __launch_bounds__(128) void gn_stats_rows16_k(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd)
+{
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
+    const int tile = blockIdx.x;
+    const f32x4* in4 = (const f32x4*)x + (size_t)tile * 512 * 4 * 32 + quad * 32 + j;
+    double S[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
+    for (int oh = 0; oh < 8; ++oh) {
+        double ts[2] = {0.0, 0.0}, tq[2] = {0.0, 0.0};
+        for (int od = 0; od < 8; ++od) {
+            f32x4 v[8];
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) v[ow] = in4[(size_t)((od * 8 + oh) * 8 + ow) * 4 * 32];
+            GnAcc a[2];
+            a[0].init(), a[1].init();
+#pragma unroll
+            for (int ow = 0; ow < 8; ++ow) a[0].add(v[ow].x), a[0].add(v[ow].y), a[1].add(v[ow].z), a[1].add(v[ow].w);
+            ts[0] += a[0].bs, tq[0] += a[0].bq, ts[1] += a[1].bs, tq[1] += a[1].bq;
+        }
+        S[0] += ts[0], Q[0] += tq[0], S[1] += ts[1], Q[1] += tq[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float m, r;
+        gn_finish(S[k], Q[k], 1.0 / 1024.0, m, r);
+        mean[((size_t)tile * 8 + 2 * quad + k) * 32 + j] = m;
+        rstd[((size_t)tile * 8 + 2 * quad + k) * 32 + j] = r;
+    }
+}
+
 // ChannelAttention gates of a tile, once, with the C/4 hidden units and the C gates of a leaf spread over the workgroup's C/4
 // (quad) threads of that leaf: the same fmaf chains as se_hidden / se_gates (vq_device.h), which every consumer wave would
 // otherwise run serially in its prologue (2 x C x C/4 fmafs behind C dependent loads).  s = this thread's 4 channel sums.
@@ -1413,16 +1437,29 @@ __global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict
 
 // Position-split launches with fused statistics: add the 16 block sums of every accumulator slot in block order (the fold()
 // chain of the one-wave-per-tile launch) and finish.  PAIR: groups of 8 channels = low quad + high quad (slots 2g, 2g+1).
-template <bool PAIR>
+template <bool PAIR, bool ROWS = false>
 __global__ __launch_bounds__(512) void gn_combine_k(const double* __restrict__ ps, const double* __restrict__ pq, float* __restrict__ mean,
                                                     float* __restrict__ rstd, int n_groups, double inv_n)
 {
     const int tile = blockIdx.x, slot = threadIdx.x >> 5, j = threadIdx.x & 31;
     double S = 0.0, Q = 0.0;
+    if (ROWS) {   // the tensor with 64 row blocks (8 slots), added row-major: conv1 output of the 16-channel residual block
+        for (int oh = 0; oh < 8; ++oh) {
+            double ts = 0.0, tq = 0.0;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-        S += ps[part_index(tile, b, slot, j)];
-        Q += pq[part_index(tile, b, slot, j)];
+            for (int od = 0; od < 8; ++od) {
+                ts += ps[part_index_rows(tile, od * 8 + oh, slot, j)];
+                tq += pq[part_index_rows(tile, od * 8 + oh, slot, j)];
+            }
+            S += ts;
+            Q += tq;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            S += ps[part_index(tile, b, slot, j)];
+            Q += pq[part_index(tile, b, slot, j)];
+        }
     }
     if (PAIR) {   // slots 2g (lanes 0..31 of the wave) and 2g+1 (lanes 32..63)
         S = S + shfl_xor32_f64(S);

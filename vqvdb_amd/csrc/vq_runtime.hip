@@ -26,6 +26,7 @@
 
 #include "../../include/vqvdb_hip.h"
 #include "vq_kernels.h"
+#include "vq_conv8_lds.h"
 #include "vq_train_kernels.h"
 #include "vq_grad_kernels.h"
 
@@ -81,6 +82,8 @@ struct vqhip_codec {
     std::string err;
     hipStream_t stream = nullptr;
     int64_t chunk = 65536;
+    int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
+    bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
     // device weights
@@ -636,7 +639,7 @@ const ActSpec kActs[] = {
     // decode: ystem (R0) -> d2 (R1) -> y4 (R2) -> x6 (R0, skip d2) -> voxels
     {"d_ystem", 64, 64, 0},    {"d_d2", 64, 64, 1},     {"d_y4", 64, 64, 2},     {"d_x6", 64, 64, 0},
     {"st_a.mean", 0, 8, -1},   {"st_a.rstd", 0, 8, -1}, {"st_b.mean", 0, 8, -1}, {"st_b.rstd", 0, 8, -1}, {"csum", 0, 64, -1}, {"gate", 0, 64, -1},
-    {"part_s", 0, 512, -1},    {"part_q", 0, 512, -1},  {"part_c", 0, 1024, -1},   // per-block statistics partials of split launches (fp64 x 256, fp32 x 1024)
+    {"part_s", 0, 1024, -1},   {"part_q", 0, 1024, -1},  {"part_c", 0, 1024, -1},   // per-block statistics partials of split launches (fp64 x 512: 16 blocks x 16 slots, or 64 rows x 8 slots; fp32 x 1024)
 };
 constexpr int kRegions = 3;
 
@@ -798,6 +801,8 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_dec_r64c2_rs, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c1_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rp, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, conv8_lds_k<false, true, 8, 0, true>, LDS_CONV8))) return rc;
+    if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
     return VQHIP_OK;
@@ -889,7 +894,8 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         L.run("enc_res16_conv1_s", [&] {
             hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]);
         });
-        combine("enc_stats_y4", 8, 1.0 / 1024.0, a["st_a.mean"], a["st_a.rstd"]);
+        // (this tensor's statistics blocks are its 64 output rows)
+        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, ps, pq, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
         // conv2 has none: a handful of tiles take two-row groups (32 ranges, half the serial chain per wave; same taps in the same order)
         const bool two = gq * 32 <= 512;   // up to 1024 leaves (measured)
         const char* tab = two ? "steps.rowgroups8_2" : "steps.rowgroups8_4";
@@ -979,14 +985,23 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rowgroups8_4"];
-        L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        if (c->conv8_lds) {   // input planes staged in LDS by a persistent workgroup per CU; statistics as 64 row partials + combine
+            A.part_s = reinterpret_cast<double*>(a["part_s"]), A.part_q = reinterpret_cast<double*>(a["part_q"]);
+            L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_lds_k<false, true, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
+            L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+        } else {   // row-group kernel: one partial per output row, added row-major by the combine
+            A.part_s = reinterpret_cast<double*>(a["part_s"]), A.part_q = reinterpret_cast<double*>(a["part_q"]);
+            L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+            L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+        }
     }
     {
         ConvArgs A{};
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rowgroups8_4"];
-        L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
+        if (c->conv8_lds) L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_lds_k<true, false, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
+        else L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
     }
     {
         ConvArgs A{};
@@ -1433,6 +1448,8 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
         c->err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
         return bail(VQHIP_ERR_DEVICE);
     }
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->err = "hipStreamCreate failed";
         return bail(VQHIP_ERR_DEVICE);
