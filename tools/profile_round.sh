@@ -7,11 +7,20 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 16 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o r01 -- python $R/bench.py --steps 16 --warmup 2 > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
-SHORT="--steps 4 --warmup 1 --no-cpu-baseline --no-train"
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r01 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r01 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o r01 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_sq.err
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o r02 -- python $R/bench.py --steps 16 --warmup 2 --no-host-path > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+SHORT="--steps 4 --warmup 1 --no-cpu-baseline --no-train --no-host-path"
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_sq.err
 find $OUT -name "*.db" | xargs ls -la
 cat $OUT/bench.json | head -c 600
+# summaries (small text / json files for profiles/); the databases themselves stay on the box
+TAG=${PROFILE_TAG:-r02_v1}
+SUM=$R/gpurun_out/prof_sum; mkdir -p $SUM
+python $R/tools/rocpd_summary.py --kt $OUT/kt/r02_results.db --fetch $OUT/pmc_fetch/r02_results.db --write $OUT/pmc_write/r02_results.db > $SUM/${TAG}_bench_rocprofv3_summary.txt
+python $R/tools/pmc_sq_summary.py $OUT/pmc_sq/r02_results.db > $SUM/${TAG}_pmc_mfma_util_clock.txt
+python $R/tools/make_traffic_json.py $OUT/pmc_fetch/r02_results.db $OUT/pmc_write/r02_results.db "profiles/${TAG}_bench_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_round.sh)" $SUM/hbm_traffic_per_launch.json
+cp $OUT/bench.json $SUM/${TAG}_bench.json; cp $OUT/bench_under_rocprof.json $SUM/${TAG}_bench_under_rocprof.json
+find $OUT -name "*.db" | xargs rm -f
+ls -la $SUM
