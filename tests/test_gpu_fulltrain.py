@@ -176,13 +176,13 @@ world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK"
 if world > 1:
     dist.init_process_group("gloo")
 c = HipCodec(weightpack.dumps(synth.make_weights(0)))
-tr = FullTrainer(c)
+tr = FullTrainer(c, overlap=os.environ.get("VQ_TEST_NO_OVERLAP") != "1")
 per = 128 // world
 for s in range(3):
     x = synth.make_leaves(128, seed=8000 + s)[rank * per:(rank + 1) * per]
     tr.step(torch.from_numpy(x).cuda())
 flat = np.concatenate([c.fulltrain_get_params(), c.train_get_state()["embedding"].reshape(-1)])
-np.save({str(tmp_path)!r} + f"/p_{{world}}_{{rank}}.npy", flat)
+np.save({str(tmp_path)!r} + f"/p_{{world}}_{{rank}}" + os.environ.get("VQ_TEST_TAG", "") + ".npy", flat)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 """)
@@ -192,8 +192,15 @@ if world > 1:
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(29800 + os.getpid() % 150), str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    # the same two-rank run with the gradient all-reduce NOT overlapped with the encoder half of the backward pass (one all-reduce of the
+    # whole vector after the backward pass): slices or whole, the sums are the same numbers
+    env2 = dict(env, VQ_TEST_NO_OVERLAP="1", VQ_TEST_TAG="_serial")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29950 + os.getpid() % 40), str(script)], capture_output=True, text=True, env=env2, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
     one, r0, r1 = (np.load(tmp_path / f) for f in ("p_1_0.npy", "p_2_0.npy", "p_2_1.npy"))
     assert np.array_equal(r0, r1)                                   # replicas stay bit-identical
+    assert np.array_equal(r0, np.load(tmp_path / "p_2_0_serial.npy"))   # overlapped == serial all-reduce
     d = np.abs(one - r0)
     assert d.max() <= 6.5e-4 and d.mean() < 5e-6, (float(d.max()), float(d.mean()))   # Adam sign-step caveat as above
 

@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
     "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
-    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info",
+    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info", "vqhip_fulltrain_fwdbwd_overlap_device", "vqhip_fulltrain_decoder_offset",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -118,6 +118,8 @@ class _GridSource(ctypes.Structure):
 GRID_BEGIN_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(_GridInfo))
 LEAF_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
                                  ctypes.POINTER(ctypes.c_void_p))
+
+PHASE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 
 _lib = None
 
@@ -163,6 +165,9 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_get_params.argtypes = [vp, vp]
     lib.vqhip_fulltrain_set_params.argtypes = [vp, vp]
     lib.vqhip_multi_worker_info.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.vqhip_fulltrain_fwdbwd_overlap_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, PHASE_FN, vp]
+    lib.vqhip_fulltrain_decoder_offset.argtypes = [vp]
+    lib.vqhip_fulltrain_decoder_offset.restype = ctypes.c_int64
     lib.vqhip_workspace_bytes.argtypes = [vp]
     lib.vqhip_workspace_bytes.restype = ctypes.c_int64
     lib.vqhip_chunk_leaves.argtypes = [vp]
@@ -188,7 +193,7 @@ def load_library() -> ctypes.CDLL:
         if getattr(lib, name).argtypes is None and name not in ("vqhip_version",):
             raise RuntimeError(f"codec.py: no argtypes declared for {name} (pointers would be truncated to 32 bits)")
         if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error",
-                        "vqhip_fulltrain_param_count", "vqhip_workspace_bytes", "vqhip_chunk_leaves"):
+                        "vqhip_fulltrain_param_count", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_fulltrain_decoder_offset"):
             getattr(lib, name).restype = ci
     _lib = lib
     return lib
@@ -403,6 +408,21 @@ class HipCodec:
 
     def fulltrain_fwdbwd_device(self, leaves_ptr: int, n: int, n_global: int, grads_ptr: int, aux_ptr: int = 0, stream: int = 0):
         self._check(self._lib.vqhip_fulltrain_fwdbwd_device(self._h, leaves_ptr, n, n_global, grads_ptr, aux_ptr or None, stream or None))
+
+    def fulltrain_fwdbwd_overlap_device(self, leaves_ptr: int, n: int, n_global: int, grads_ptr: int, aux_ptr: int, stream: int, decoder_done):
+        """fwdbwd with `decoder_done()` called once the decoder half of the backward pass is enqueued (see vqvdb_hip.h)."""
+        def cb(_user):
+            try:
+                decoder_done()
+                return 0
+            except Exception as e:  # noqa: BLE001 — an exception must not unwind through the C frames
+                print(f"fulltrain decoder_done callback: {e}", file=sys.stderr)
+                return 1
+        fn = PHASE_FN(cb)
+        self._check(self._lib.vqhip_fulltrain_fwdbwd_overlap_device(self._h, leaves_ptr, n, n_global, grads_ptr, aux_ptr or None, stream or None, fn, None))
+
+    def fulltrain_decoder_offset(self) -> int:
+        return int(self._lib.vqhip_fulltrain_decoder_offset(self._h))
 
     def fulltrain_apply_device(self, grads_ptr: int, aux_ptr: int, lr: float, step: int, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                                weight_decay: float = 1e-4, ema_decay: float = 0.95, ema_eps: float = 1e-4, stream: int = 0):

@@ -49,7 +49,7 @@ class FullTrainer:
 
     def __init__(self, codec, lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 1e-4,
                  commitment_cost: float = 0.25, ema_decay: float = 0.95, ema_eps: float = 1e-4, t_max: Optional[int] = None, group=None,
-                 device: str = "cuda"):
+                 device: str = "cuda", overlap: bool = True):
         self.codec, self.group, self.device = codec, group, torch.device(device)
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         self.commitment_cost, self.ema_decay, self.ema_eps, self.t_max = commitment_cost, ema_decay, ema_eps, t_max
@@ -59,6 +59,8 @@ class FullTrainer:
         self.grads = torch.zeros(codec.fulltrain_param_count(), dtype=torch.float32, device=self.device)
         self.aux = torch.zeros(AUX_FLOATS, dtype=torch.float32, device=self.device)
         self.stream = torch.cuda.Stream(device=self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device)   # all-reduce of the decoder's gradients, overlapped with the encoder backward
+        self.overlap = overlap
         self.steps_done = 0
 
     def _world(self) -> int:
@@ -78,10 +80,29 @@ class FullTrainer:
         out = None
         with torch.cuda.stream(self.stream):
             h = self.stream.cuda_stream
-            self.codec.fulltrain_fwdbwd_device(leaves.data_ptr(), n, n * world, self.grads.data_ptr(), self.aux.data_ptr(), stream=h)
-            if world > 1:
-                dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+            if world > 1 and self.overlap:
+                # the decoder's gradients (69 % of the vector) are final once the decoder half of the backward pass is enqueued: their
+                # all-reduce runs on its own stream while the encoder half computes; encoder slice + statistics follow on this stream
+                dec = self.codec.fulltrain_decoder_offset()
+                pending = []
+
+                def decoder_done():
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    self.comm_stream.wait_event(ev)
+                    with torch.cuda.stream(self.comm_stream):
+                        pending.append(dist.all_reduce(self.grads[dec:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.codec.fulltrain_fwdbwd_overlap_device(leaves.data_ptr(), n, n * world, self.grads.data_ptr(), self.aux.data_ptr(), h, decoder_done)
+                dist.all_reduce(self.grads[:dec], op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(self.aux, op=dist.ReduceOp.SUM, group=self.group)
+                for w in pending:
+                    w.wait()                                  # this stream waits for the decoder slice
+                self.stream.wait_stream(self.comm_stream)
+            else:
+                self.codec.fulltrain_fwdbwd_device(leaves.data_ptr(), n, n * world, self.grads.data_ptr(), self.aux.data_ptr(), stream=h)
+                if world > 1:
+                    dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(self.aux, op=dist.ReduceOp.SUM, group=self.group)
             self.codec.fulltrain_apply_device(self.grads.data_ptr(), self.aux.data_ptr(), lr, self.steps_done + 1, self.betas, self.adam_eps,
                                               self.weight_decay, self.ema_decay, self.ema_eps, stream=h)
             if want_metrics:
