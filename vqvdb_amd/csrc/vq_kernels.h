@@ -1289,6 +1289,173 @@ __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ id
 }
 
 // ------------------------------------------------------------------------------------------
+// D0-D2 fused (large passes): embedding gather + decoder stem conv (as stem_lut_k) + GroupNorm(8,64) + ReLU (VQVAE_v2.py:258-259)
+// + the statistics of the result for ResidualBlock.gn1 (:205), in ONE kernel: the stem output never goes to HBM.
+// GroupNorm needs the statistics of the whole leaf before any element can be normalised, so a workgroup owns FOUR leaves for all 64
+// positions: phase 1 gathers (wave w = positions 8w .. 8w+7, lane = (leaf, 16-byte chunk), a leaf's 16 lanes read the whole
+// 256-byte table row) into a 64 KB LDS tile and chains the statistics per 4-position block; the 16 block sums are added in order
+// through LDS (the 16-block rule, same numbers as stem_lut_k); phase 2 normalises out of LDS, stores d2 in the L4 layout and chains
+// the statistics of d2 (same decomposition as gn_relu_stats_k: one accumulator per channel quad).  80 KB of LDS -> two workgroups
+// per CU: one gathers (L1-bound) while the other writes (HBM-bound).  Replaces stem_lut_k + gn_relu_stats_k: 1 GB less written,
+// 1 GB less read per 65 536 leaves.
+// ------------------------------------------------------------------------------------------
+struct StemFusedArgs {
+    const uint8_t* idx;
+    const float* T;          // (tap, code) table [27][256][64]
+    const float* bias;       // stem bias [64]
+    const float* gamma;      // stem GroupNorm weight / bias [64]
+    const float* beta;
+    float* d2;               // out: relu(GroupNorm(stem)) L4 [tile][64][16][32][4]
+    float* out_mean;         // statistics of d2 for the residual block's gn1: [tile][8][32]
+    float* out_rstd;
+    float* ystem_dbg;        // optional: raw stem output (debug fetch), same layout as d2
+    const int4* steps;
+    const int* grp_start;
+    int n_steps;
+    int64_t n_leaves;
+    int n_tiles;
+};
+
+__global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
+{
+    __shared__ f32x4 ys[64 * 4 * 16];          // [pos][leaf 4][chunk 16]
+    __shared__ double part[16][64];            // [block][lane of (leaf, chunk)]: the sums, then (after a barrier) the sums of squares —
+                                               // 8 KB instead of 16: 74 KB per workgroup, two workgroups per CU
+    __shared__ uint8_t sidx[4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x >> 3, lg = blockIdx.x & 7;
+    const int l = lane >> 4, c = lane & 15;
+    const int jt = 4 * lg + l;
+    if (tid < 256) {
+        const int64_t leaf = (int64_t)tile * 32 + 4 * lg + (tid >> 6);
+        sidx[tid >> 6][tid & 63] = leaf < A.n_leaves ? A.idx[leaf * 64 + (tid & 63)] : 0;
+    }
+    __syncthreads();
+    const f32x4* T4 = (const f32x4*)A.T + c;
+    const f32x4 b4 = ((const f32x4*)A.bias)[c];
+    const uint8_t* my = sidx[l];
+
+    // ---- phase 1: gather + bias -> LDS, statistics per 4-position block ----
+    double bs0 = 0.0, bq0 = 0.0, bs1 = 0.0, bq1 = 0.0;   // this wave's two blocks (2w, 2w+1) of the tensor being reduced
+    // ordered sum of the 16 blocks of every lane's accumulator: sums through LDS, barrier, sums of squares through the same buffer
+    auto ordered_totals = [&](double& S, double& Q) {
+        part[2 * wave][lane] = bs0, part[2 * wave + 1][lane] = bs1;
+        __syncthreads();
+        S = 0.0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) S += part[b][lane];
+        __syncthreads();
+        part[2 * wave][lane] = bq0, part[2 * wave + 1][lane] = bq1;
+        __syncthreads();
+        Q = 0.0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) Q += part[b][lane];
+        __syncthreads();
+    };
+    {
+        const int g0 = wave * 8, g1 = g0 + 8;
+        int si = A.grp_start[g0];
+        const int NSm = A.n_steps - 1;
+        int4 e = A.steps[si], e1 = A.steps[min(si + 1, NSm)], e2 = A.steps[min(si + 2, NSm)], e3 = A.steps[min(si + 3, NSm)];
+#define STEMF_ROW(E) T4[((size_t)(E).y * 256 + my[(E).x]) * 16]
+        f32x4 r0 = STEMF_ROW(e), r1 = STEMF_ROW(e1), r2 = STEMF_ROW(e2), r3;
+        int po = g0;
+        f32x4 acc = {0, 0, 0, 0};
+        GnAcc st;
+        st.init();
+        bool done = false;
+        // (the wave's two block sums wait in registers: blk[0], blk[1])
+#define STEMF_STEP(RC, RN)                                                        \
+    if (!done) {                                                                  \
+        RN = STEMF_ROW(e3);                                                       \
+        const int4 e4 = A.steps[min(si + 4, NSm)];                                \
+        acc = acc + RC;                                                           \
+        const bool last = (e.w & 2) != 0;                                         \
+        e = e1, e1 = e2, e2 = e3, e3 = e4;                                        \
+        ++si;                                                                     \
+        if (last) {                                                               \
+            const f32x4 v = acc + b4;                                             \
+            ys[(po * 4 + l) * 16 + c] = v;                                        \
+            st.add(v.x);                                                          \
+            st.add(v.y);                                                          \
+            st.add(v.z);                                                          \
+            st.add(v.w);                                                          \
+            acc = (f32x4){0, 0, 0, 0};                                            \
+            if ((po & 3) == 3) {                                                  \
+                if (po & 4) bs1 = st.bs, bq1 = st.bq;                             \
+                else bs0 = st.bs, bq0 = st.bq;                                    \
+                st.init();                                                        \
+            }                                                                     \
+            done = ++po == g1;                                                    \
+        }                                                                         \
+    }
+        while (!done) {
+            STEMF_STEP(r0, r3)
+            STEMF_STEP(r1, r0)
+            STEMF_STEP(r2, r1)
+            STEMF_STEP(r3, r2)
+        }
+#undef STEMF_STEP
+#undef STEMF_ROW
+    }
+    // the 16 block sums in order, then low quad + high quad of the 8-channel group (lanes c and c ^ 1)
+    float ia[4], ib[4];
+    {
+        double S, Q;
+        ordered_totals(S, Q);   // (its barriers also make the LDS tile visible to phase 2)
+        const double S2 = __shfl_xor(S, 1, 64), Q2 = __shfl_xor(Q, 1, 64);
+        float m, r;
+        gn_finish((c & 1) ? S2 + S : S + S2, (c & 1) ? Q2 + Q : Q + Q2, 1.0 / 512.0, m, r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ia[i] = r * A.gamma[4 * c + i];
+            ib[i] = __builtin_fmaf(-m, ia[i], A.beta[4 * c + i]);
+        }
+    }
+
+    // ---- phase 2: normalise + ReLU out of LDS -> d2, statistics of d2 per block ----
+    {
+        f32x4* out4 = (f32x4*)A.d2 + ((size_t)tile * 64 * 16 + c) * 32 + jt;
+        f32x4* dbg4 = A.ystem_dbg ? (f32x4*)A.ystem_dbg + ((size_t)tile * 64 * 16 + c) * 32 + jt : nullptr;
+        GnAcc st;
+        st.init();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int po = wave * 8 + k;
+            const f32x4 v = ys[(po * 4 + l) * 16 + c];
+            if (dbg4) dbg4[(size_t)po * 16 * 32] = v;
+            f32x4 y;
+            y.x = fmaxf(__builtin_fmaf(v.x, ia[0], ib[0]), 0.0f);
+            y.y = fmaxf(__builtin_fmaf(v.y, ia[1], ib[1]), 0.0f);
+            y.z = fmaxf(__builtin_fmaf(v.z, ia[2], ib[2]), 0.0f);
+            y.w = fmaxf(__builtin_fmaf(v.w, ia[3], ib[3]), 0.0f);
+            out4[(size_t)po * 16 * 32] = y;
+            st.add(y.x);
+            st.add(y.y);
+            st.add(y.z);
+            st.add(y.w);
+            if ((k & 3) == 3) {
+                if (k & 4) bs1 = st.bs, bq1 = st.bq;
+                else bs0 = st.bs, bq0 = st.bq;
+                st.init();
+            }
+        }
+    }
+    {
+        double S, Q;
+        ordered_totals(S, Q);
+        const double S2 = __shfl_xor(S, 1, 64), Q2 = __shfl_xor(Q, 1, 64);
+        if (wave == 0 && (c & 1) == 0) {
+            float m, r;
+            gn_finish(S + S2, Q + Q2, 1.0 / 512.0, m, r);
+            A.out_mean[((size_t)tile * 8 + (c >> 1)) * 32 + jt] = m;
+            A.out_rstd[((size_t)tile * 8 + (c >> 1)) * 32 + jt] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Stand-alone statistics of a stored activation, by the 16-block rule (same results as the fused ones).  The training step uses
 // them (its forward keeps every activation and recomputes the statistics the backward pass needs); the inference split path
 // fuses its statistics as per-block partials instead.

@@ -65,7 +65,8 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"enc_res32_conv1", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
         {"enc_res32_conv2", {2.0 * 1769472, 2.0 * 1769472 * 0.578704}},
         {"enc_vq", {2.0 * (262144 + 2097152 + 512), 2.0 * (524288 + 512)}},  // attn + proj + VQ; projection folded into the search
-        {"dec_stem", {0.0, 0.0}},  // table lookups: the 14.2 M MAC/leaf of the reference op are not executed (stem_lut_k)
+        {"dec_stem", {0.0, 0.0}},
+        {"dec_stem_gn", {0.0, 0.0}},  // table lookups: the 14.2 M MAC/leaf of the reference op are not executed (stem_lut_k)
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         // folded up_conv+pixshuf+final: nominal = the reference ops' dense count; "effective" = the MACs the
@@ -83,6 +84,7 @@ struct vqhip_codec {
     hipStream_t stream = nullptr;
     int64_t chunk = 65536;
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
+    bool stem_fused = true;  // decoder front of large passes: stem_fused_k; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
@@ -1110,15 +1112,24 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
 
     if (use_split(c, nt, true)) return decode_chunk_split(c, L, d_idx, n, d_out, s);
-    L.run("dec_stem", [&] {
-        hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
-                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
-    });
-    {
-        ConvArgs A{};
-        A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
-        A.in_gamma = w["dg0.w"], A.in_beta = w["dg0.b"], A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
-        L.run("dec_gn_relu_stats", [&] { hipLaunchKernelGGL((gn_relu_stats_k<64, 64, 8>), dim3(g4), dim3(256), 0, s, A); });
+    if (c->stem_fused) {   // gather + stem + GroupNorm + ReLU + statistics in one kernel: the stem output stays in LDS
+        StemFusedArgs F{};
+        F.idx = d_idx, F.T = w["ds.lut"], F.bias = w["ds.b"], F.gamma = w["dg0.w"], F.beta = w["dg0.b"], F.d2 = a["d_d2"];
+        F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
+        F.steps = (const int4*)w["steps.k3s1_4"], F.grp_start = reinterpret_cast<const int*>(w["steps.k3s1_4.grp"]), F.n_steps = c->nsteps["steps.k3s1_4"];
+        F.n_leaves = n, F.n_tiles = nt;
+        L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_fused_k, dim3(8 * nt), dim3(512), 0, s, F); });
+    } else {
+        L.run("dec_stem", [&] {
+            hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
+                               (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, (const int*)nullptr);
+        });
+        {
+            ConvArgs A{};
+            A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
+            A.in_gamma = w["dg0.w"], A.in_beta = w["dg0.b"], A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
+            L.run("dec_gn_relu_stats", [&] { hipLaunchKernelGGL((gn_relu_stats_k<64, 64, 8>), dim3(g4), dim3(256), 0, s, A); });
+        }
     }
     {
         ConvArgs A{};
@@ -1450,6 +1461,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     }
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0;
+    if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->err = "hipStreamCreate failed";
         return bail(VQHIP_ERR_DEVICE);
