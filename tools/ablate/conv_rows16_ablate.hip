@@ -1,0 +1,64 @@
+// Where does the decoder's 64 -> 64 conv (conv_rows16_k, streamed weights) lose its 16 % to the MFMA peak?  Timing-only variants.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I vqvdb_amd/csrc tools/ablate/conv_rows16_ablate.hip -o tools/ablate/bin/ablate_r16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "vq_kernels.h"
+
+static std::vector<int> steps_rows(int SI, int SO, int KS, int STRIDE, int PAD)
+{
+    std::vector<int> t;
+    for (int od = 0; od < SO; ++od)
+        for (int oh = 0; oh < SO; ++oh) {
+            const size_t first = t.size();
+            for (int kd = 0; kd < KS; ++kd)
+                for (int kh = 0; kh < KS; ++kh) {
+                    const int id = od * STRIDE - PAD + kd, ih = oh * STRIDE - PAD + kh;
+                    if (id < 0 || id >= SI || ih < 0 || ih >= SI) continue;
+                    t.insert(t.end(), {(id * SI + ih) * SI, (kd * KS + kh) * KS, (od * SO + oh) * SO, 1 << 8});
+                }
+            t[first + 3] |= 1;
+            t[t.size() - 1] |= 2;
+        }
+    return t;
+}
+
+constexpr size_t LDS = (size_t)2 * (3 * 16 * 64) * 16;
+template <typename K>
+static void run(const char* name, K k, ConvArgs A, const int4* steps, int nt)
+{
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDS, 0, A, steps);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDS, 0, A, steps);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    printf("%-56s %8.4f ms  (%s)\n", name, ms / 5, hipGetErrorString(hipGetLastError()));
+}
+
+int main()
+{
+    const int nt = 2048;
+    const size_t act = (size_t)nt * 64 * 64 * 32 * 4;
+    float *in, *out, *mean, *rstd, *om, *orr, *w, *bias, *gam, *bet;
+    hipMalloc(&in, act), hipMalloc(&out, act);
+    hipMalloc(&mean, (size_t)nt * 8 * 32 * 4), hipMalloc(&rstd, (size_t)nt * 8 * 32 * 4), hipMalloc(&om, (size_t)nt * 8 * 32 * 4), hipMalloc(&orr, (size_t)nt * 8 * 32 * 4);
+    hipMalloc(&w, (size_t)27 * 16 * 64 * 16), hipMalloc(&bias, 256), hipMalloc(&gam, 256), hipMalloc(&bet, 256);
+    hipMemset(in, 0, act), hipMemset(mean, 0, (size_t)nt * 8 * 32 * 4), hipMemset(rstd, 0, (size_t)nt * 8 * 32 * 4);
+    hipMemset(w, 0, (size_t)27 * 16 * 64 * 16), hipMemset(bias, 0, 256), hipMemset(gam, 0, 256), hipMemset(bet, 0, 256);
+    std::vector<int> t = steps_rows(4, 4, 3, 1, 1);
+    int4* steps;
+    hipMalloc(&steps, t.size() * 4);
+    hipMemcpy(steps, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+    ConvArgs A{};
+    A.in = in, A.out = out, A.wfrag = w, A.bias_frag = bias, A.in_mean = mean, A.in_rstd = rstd, A.in_gamma = gam, A.in_beta = bet;
+    A.out_mean = om, A.out_rstd = orr, A.n_tiles = nt, A.n_steps = (int)t.size() / 4, A.n_taps = 27;
+#define R(ABL) run("dec res64 conv1, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL>, A, steps, nt)
+    // ABL bits: 1 no barriers, 2 no weight streaming, 4 no LDS A reads, 8 no activation re-loads, 16 no GN transform, 32 no epilogue
+    R(0); R(1); R(2); R(3); R(4); R(8); R(16); R(32); R(7); R(15); R(31); R(63);
+    return 0;
+}

@@ -845,9 +845,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false>
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
+    // ABL: timing-only ablations for tools/ablate/conv_rows16_ablate.hip (0 in the library): 1 no barriers, 2 no weight streaming,
+    // 4 no LDS A-fragment reads, 8 no activation re-loads, 16 no GroupNorm transform, 32 no epilogue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int CBN = CIN / 16, MTN = COUT / 16, NPI = SI * SI * SI, NPO = SO * SO * SO;
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         bool last;
         do {
-            if (INMODE == 1 && work) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
+            if (INMODE == 1 && work && !(ABL & 16)) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
 #pragma unroll
                 for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
@@ -945,9 +947,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
             if (!RESIDENT) {
                 __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight pieces and input row have landed
-                __syncthreads();                      // every wave's pieces of W(step) landed; every wave done reading W(step-1)
+                if (!(ABL & 1)) __syncthreads();      // every wave's pieces of W(step) landed; every wave done reading W(step-1)
                 f32x4* dst = lds + ((si + 1) & 1) * WSTEPL;
-                for (int t = wave; t < WSTEPL / 64; t += NWV) {
+                for (int t = wave; t < ((ABL & 2) ? 0 : WSTEPL / 64); t += NWV) {
                     const int piece = (t / MTL) * MTN + mz + t % MTL;
                     glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + t * 64);
                 }
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                     for (int cb = 0; cb < CBN; ++cb) {
                         f32x4 a[MTL];   // the cout tiles of this (tap, channel block): MTN LDS reads ahead of their MFMAs, no further
 #pragma unroll
-                        for (int mt = 0; mt < MTL; ++mt) a[mt] = wl[((kw * CBN + cb) * MTL + mt) * 64];
+                        for (int mt = 0; mt < MTL; ++mt) a[mt] = (ABL & 4) ? xr[(iw + mt) % SI][cb] : wl[((kw * CBN + cb) * MTL + mt) * 64];
 #pragma unroll
                         for (int mt = 0; mt < MTL; ++mt) {
                             acc[ow][mt] = mfma16(a[mt].x, xr[iw][cb].x, acc[ow][mt]);
@@ -980,7 +982,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                     if (PF2) {
                         xr[iw][cb] = xq[iw][cb];
                         xq[iw][cb] = in4[((size_t)(en2.x + iw) * (CIN / 4) + 4 * cb) * 32];   // the row after next (index clamped)
-                    } else {
+                    } else if (!(ABL & 8)) {
                         xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
                     }
                 }
@@ -991,6 +993,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             ++si;
         } while (!last);
         // ---- epilogue: the SO positions of the row, ascending ----
+        if (ABL & 32) {   // keep the accumulators alive, nothing else
+            float t = 0.0f;
+#pragma unroll
+            for (int ow = 0; ow < SO; ++ow)
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt) t += acc[ow][mt].x + acc[ow][mt].w;
+            if (t == 12345.678f) out4[0] = acc[0][0];
+            continue;
+        }
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow) {
             const size_t o = ((size_t)(row * SO + ow) * (COUT / 4)) * 32;
