@@ -59,6 +59,8 @@ int main()
     A.out_mean = om, A.out_rstd = orr, A.n_tiles = nt, A.n_steps = (int)t.size() / 4, A.n_taps = 27;
 #define R(ABL) run("dec res64 conv1, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL>, A, steps, nt)
     // ABL bits: 1 no barriers, 2 no weight streaming, 4 no LDS A reads, 8 no activation re-loads, 16 no GN transform, 32 no epilogue
-    R(0); R(1); R(2); R(3); R(4); R(8); R(16); R(32); R(7); R(15); R(31); R(63);
+    R(0); R(1); R(2); R(8); R(32); R(63);
+#define RK(ABL) run("dec res64 conv1, kw-outer, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL, true>, A, steps, nt)
+    RK(0); RK(1); RK(2); RK(8); RK(32); RK(63);
     return 0;
 }

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0>
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0, bool KWO = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     // ABL: timing-only ablations for tools/ablate/conv_rows16_ablate.hip (0 in the library): 1 no barriers, 2 no weight streaming,
@@ -955,6 +955,55 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                 }
             }
             const f32x4* wl = (RESIDENT ? lds + (size_t)e.y * WTAPL : lds + (si & 1) * WSTEPL) + lane;
+            if (KWO) {
+                // kw-outer order: the A fragments of one (kw, pair of channel blocks) are read once from LDS and feed every output of the
+                // row that has this kw (3-4 outputs x 2 blocks x MTL x 4 MFMAs per 2*MTL ds_read_b128, instead of one block's MTL x 4).
+                // Per output the taps still arrive with kw ascending and, inside a tap, the channel blocks ascending: same arithmetic.
+                static_assert(!KWO || (CBN % 2 == 0 && !PF2), "kw-outer: pairs of channel blocks, single rolling buffer");
+                if (work) {
+#pragma unroll
+                    for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+                        for (int cbp = 0; cbp < CBN; cbp += 2) {
+                            f32x4 a[2][MTL];
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                                for (int mt = 0; mt < MTL; ++mt) a[c2][mt] = wl[((kw * CBN + cbp + c2) * MTL + mt) * 64];
+#pragma unroll
+                            for (int ow = 0; ow < SO; ++ow) {
+                                const int iw = ow * STRIDE - PAD + kw;
+                                if (iw < 0 || iw >= SI) continue;
+#pragma unroll
+                                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                                    for (int mt = 0; mt < MTL; ++mt) {
+                                        acc[ow][mt] = mfma16(a[c2][mt].x, xr[iw][cbp + c2].x, acc[ow][mt]);
+                                        acc[ow][mt] = mfma16(a[c2][mt].y, xr[iw][cbp + c2].y, acc[ow][mt]);
+                                        acc[ow][mt] = mfma16(a[c2][mt].z, xr[iw][cbp + c2].z, acc[ow][mt]);
+                                        acc[ow][mt] = mfma16(a[c2][mt].w, xr[iw][cbp + c2].w, acc[ow][mt]);
+                                    }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // positions whose last tap of the row was this kw: re-load for the next step
+#pragma unroll
+                        for (int iw = 0; iw < SI; ++iw) {
+                            int lastkw = -1;
+#pragma unroll
+                            for (int k2 = 0; k2 < KS; ++k2) {
+                                const int num = iw + PAD - k2;
+                                if (num >= 0 && num % STRIDE == 0 && num / STRIDE < SO) lastkw = k2;
+                            }
+                            if (lastkw == kw || (lastkw < 0 && kw == 0)) {
+#pragma unroll
+                                for (int cb = 0; cb < CBN; ++cb)
+                                    if (!(ABL & 8)) xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
+                            }
+                        }
+                    }
+                }
+            } else
             if (work)
 #pragma unroll
             for (int iw = 0; iw < SI; ++iw) {

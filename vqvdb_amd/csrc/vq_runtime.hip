@@ -759,8 +759,9 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 //                                        CIN COUT SI SO KS ST PD NW INMODE GIN RESID GOUT CSUM
 constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
 //                                           CIN COUT SI SO KS ST PD INMODE RESID GOUT CSUM
-constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false>;   // row-blocked 16x16x4 convs (4^3 outputs)
-constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true>;
+// large passes: kw-outer MFMA order (A fragments of a (kw, channel-block pair) read once for every output of the row)
+constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, 0, true>;   // row-blocked 16x16x4 convs (4^3 outputs)
+constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, false, 0, true>;
 constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (training forward, data gradients)
 constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
 // position-split inference launches: fused statistics as per-block partials (PARTS)
