@@ -959,15 +959,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                 // kw-outer order: the A fragments of one (kw, pair of channel blocks) are read once from LDS and feed every output of the
                 // row that has this kw (3-4 outputs x 2 blocks x MTL x 4 MFMAs per 2*MTL ds_read_b128, instead of one block's MTL x 4).
                 // Per output the taps still arrive with kw ascending and, inside a tap, the channel blocks ascending: same arithmetic.
-                static_assert(!KWO || (CBN % 2 == 0 && !PF2), "kw-outer: pairs of channel blocks, single rolling buffer");
+                static_assert(!KWO || !PF2, "kw-outer: single rolling buffer");
+                constexpr int CP = CBN % 2 == 0 ? 2 : 1;   // channel blocks per A-fragment group
                 if (work) {
 #pragma unroll
                     for (int kw = 0; kw < KS; ++kw) {
 #pragma unroll
-                        for (int cbp = 0; cbp < CBN; cbp += 2) {
-                            f32x4 a[2][MTL];
+                        for (int cbp = 0; cbp < CBN; cbp += CP) {
+                            f32x4 a[CP][MTL];
 #pragma unroll
-                            for (int c2 = 0; c2 < 2; ++c2)
+                            for (int c2 = 0; c2 < CP; ++c2)
 #pragma unroll
                                 for (int mt = 0; mt < MTL; ++mt) a[c2][mt] = wl[((kw * CBN + cbp + c2) * MTL + mt) * 64];
 #pragma unroll
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                                 const int iw = ow * STRIDE - PAD + kw;
                                 if (iw < 0 || iw >= SI) continue;
 #pragma unroll
-                                for (int c2 = 0; c2 < 2; ++c2)
+                                for (int c2 = 0; c2 < CP; ++c2)
 #pragma unroll
                                     for (int mt = 0; mt < MTL; ++mt) {
                                         acc[ow][mt] = mfma16(a[c2][mt].x, xr[iw][cbp + c2].x, acc[ow][mt]);
