@@ -43,7 +43,7 @@ static void run(const char* name, K k, ConvArgs A, const int4* steps, int nt)
 int main()
 {
     const int nt = 2048;
-    const size_t act = (size_t)nt * 64 * 64 * 32 * 4;
+    const size_t act = (size_t)nt * 512 * 16 * 32 * 4 + 4096;   // large enough for every layer tested here (16 ch @ 8^3)
     float *in, *out, *mean, *rstd, *om, *orr, *w, *bias, *gam, *bet;
     hipMalloc(&in, act), hipMalloc(&out, act);
     hipMalloc(&mean, (size_t)nt * 8 * 32 * 4), hipMalloc(&rstd, (size_t)nt * 8 * 32 * 4), hipMalloc(&om, (size_t)nt * 8 * 32 * 4), hipMalloc(&orr, (size_t)nt * 8 * 32 * 4);
@@ -62,5 +62,36 @@ int main()
     R(0); R(1); R(2); R(8); R(32); R(63);
 #define RK(ABL) run("dec res64 conv1, kw-outer, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL, true>, A, steps, nt)
     RK(0); RK(1); RK(2); RK(8); RK(32); RK(63);
+    {   // encoder res32 conv1: 32 -> 32 k3 @4^3, weights LDS-resident (108 KB), 16 waves
+        std::vector<int> t2 = steps_rows(4, 4, 3, 1, 1);
+        ConvArgs B = A;
+        B.n_taps = 27;
+        constexpr size_t LDS32 = (size_t)27 * (2 * 2 * 64) * 16;
+#define R32(ABL) { auto k = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 16, false, ABL>; \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32); \
+        hipEvent_t a, b; hipEventCreate(&a), hipEventCreate(&b); \
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 15) / 16), dim3(1024), LDS32, 0, B, steps); \
+        hipEventRecord(a, 0); for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 15) / 16), dim3(1024), LDS32, 0, B, steps); \
+        hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); \
+        printf("enc res32 conv1, ABL %-3d                                  %8.4f ms  (%s)\n", ABL, ms / 5, hipGetErrorString(hipGetLastError())); }
+        R32(0) R32(4) R32(8) R32(16) R32(32) R32(60)
+    }
+    {   // encoder down conv: 16 -> 32 k4 s2 @8^3 -> 4^3, weights LDS-resident (128 KB), 8 waves, two-step prefetch
+        std::vector<int> t3 = steps_rows(8, 4, 4, 2, 1);
+        int4* steps3;
+        hipMalloc(&steps3, t3.size() * 4);
+        hipMemcpy(steps3, t3.data(), t3.size() * 4, hipMemcpyHostToDevice);
+        ConvArgs B = A;
+        B.n_taps = 64, B.n_steps = (int)t3.size() / 4;
+        constexpr size_t LDSD = (size_t)64 * (1 * 2 * 64) * 16;
+#define RD(ABL) { auto k = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, true, 8, false, ABL>; \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSD); \
+        hipEvent_t a, b; hipEventCreate(&a), hipEventCreate(&b); \
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDSD, 0, B, steps3); \
+        hipEventRecord(a, 0); for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDSD, 0, B, steps3); \
+        hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); \
+        printf("enc down, ABL %-3d                                         %8.4f ms  (%s)\n", ABL, ms / 5, hipGetErrorString(hipGetLastError())); }
+        RD(0) RD(4) RD(8) RD(32) RD(44)
+    }
     return 0;
 }
