@@ -22,6 +22,13 @@
 #pragma once
 #include "vq_kernels.h"
 
+// workgroup barrier that waits for this wave's LDS operations only: s_waitcnt lgkmcnt(0) (vmcnt / expcnt fields at their maxima) + s_barrier
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+}
+
 constexpr size_t LDS_CONV8 = (size_t)(27 * 64 + 2 * 4096) * 16;   // 155 648 B
 
 // ABL: timing-only ablations for tools/ablate/conv8_lds_ablate.hip (0 in the library): 1 no barriers, 2 no epilogue, 4 no plane
@@ -152,7 +159,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
 #pragma unroll
         for (int ow = 0; ow < OWN; ++ow) acc[ow] = (f32x4){0, 0, 0, 0};
         if (od > 0) taps(slots + ((P - 1) & 1) * 4096, 0);
-        if (!(ABL & 1)) __syncthreads();   // every wave is done with plane od-1 (and, at od = 0, plane 0 written before this barrier is visible)
+        // barriers order LDS traffic only: wait for this wave's LDS operations (lgkmcnt), NOT for its global stores / prefetches in
+        // flight (vmcnt) as __syncthreads() would — the epilogue's stores of the previous plane are still on their way here
+        if (!(ABL & 1)) lds_barrier();   // every wave is done with plane od-1 (and, at od = 0, plane 0 written before this barrier is visible)
         if (P + 1 < NPL && !(ABL & 4)) {
             write_plane(P + 1);                      // ... into the slot plane od-1 just left (next half tile's plane 0 at od = 7)
             if (P + 2 < NPL) issue_prefetch(P + 2);   // two planes ahead: a whole plane of MFMAs hides the latency
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
             for (int ow = 0; ow < OWN; ++ow) sk[ow] = skip4[(size_t)((od * 8 + oh) * 8 + ow0 + ow) * 4 * 32];
         }
         taps(slots + (P & 1) * 4096, 1);
-        if (!(ABL & 1)) __syncthreads();   // plane od+1 is visible
+        if (!(ABL & 1)) lds_barrier();   // plane od+1 is visible
         if (od < 7) taps(slots + ((P + 1) & 1) * 4096, 2);
 
         // ---- epilogue: this wave's positions of row (od, oh), ascending ----
