@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
                 const f32x4 u = v * 0.1f;
                 v = sk[ow] + u;
             }
-            if (!(ABL & 2)) out4[(size_t)((od * 8 + oh) * 8 + ow0 + ow) * 4 * 32] = v;
+            if (!(ABL & 2)) __builtin_nontemporal_store(v, &out4[(size_t)((od * 8 + oh) * 8 + ow0 + ow) * 4 * 32]);   // streaming: read by the next kernel from HBM anyway
             if ((ABL & 2) && ow == 0 && v.x == 12345.678f) out4[0] = v;   // keep the accumulators alive
             if (STATS && !(ABL & 2)) {
                 st[0].add(v.x);
