@@ -1029,6 +1029,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
         L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
+
     if (d_latent) {
         launch_latent_assign(c, L, n, d_idx, d_latent, s, 1);
         return L.rc;
