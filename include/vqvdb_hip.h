@@ -209,6 +209,11 @@ int vqhip_train_commit(vqhip_codec* codec);
 #define VQHIP_FULLTRAIN_AUX_FLOATS (VQHIP_VQ_STATS_FLOATS + 3) /* VQ statistics | sum (recon-x)^2 | sum |recon-x| | voxels */
 int vqhip_fulltrain_begin(vqhip_codec* codec);
 int64_t vqhip_fulltrain_param_count(const vqhip_codec* codec);
+/* The decoder tail (up_conv -> PixelShuffle3D -> final) is linear in its input and bilinear in its weights; by default (1) the training
+ * step runs it as ONE folded operator, forward and backward, like inference does (vq_train_tail.h: fragments rebuilt on the device every
+ * step, data gradient through the transposed operator, weight gradients by the chain rule through the fold).  0 selects the
+ * layer-by-layer tail (every intermediate tensor and its gradient materialised: what the per-tensor gradient tests look at). */
+int vqhip_fulltrain_set_folded_tail(vqhip_codec* codec, int on);
 /* Training-mode forward only (test hook): every activation stays in the workspaces for vqhip_debug_fetch. */
 int vqhip_fulltrain_forward_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, void* hip_stream);
 int vqhip_fulltrain_fwdbwd_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, int64_t n_global_leaves, float* grads_dev,

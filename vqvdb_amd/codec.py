@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
     "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
-    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info", "vqhip_fulltrain_fwdbwd_overlap_device", "vqhip_fulltrain_decoder_offset",
+    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info", "vqhip_fulltrain_fwdbwd_overlap_device", "vqhip_fulltrain_decoder_offset", "vqhip_fulltrain_set_folded_tail",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -166,6 +166,7 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_set_params.argtypes = [vp, vp]
     lib.vqhip_multi_worker_info.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.vqhip_fulltrain_fwdbwd_overlap_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, PHASE_FN, vp]
+    lib.vqhip_fulltrain_set_folded_tail.argtypes = [vp, ci]
     lib.vqhip_fulltrain_decoder_offset.argtypes = [vp]
     lib.vqhip_fulltrain_decoder_offset.restype = ctypes.c_int64
     lib.vqhip_workspace_bytes.argtypes = [vp]
@@ -420,6 +421,9 @@ class HipCodec:
                 return 1
         fn = PHASE_FN(cb)
         self._check(self._lib.vqhip_fulltrain_fwdbwd_overlap_device(self._h, leaves_ptr, n, n_global, grads_ptr, aux_ptr or None, stream or None, fn, None))
+
+    def fulltrain_set_folded_tail(self, on: bool):
+        self._check(self._lib.vqhip_fulltrain_set_folded_tail(self._h, int(on)))
 
     def fulltrain_decoder_offset(self) -> int:
         return int(self._lib.vqhip_fulltrain_decoder_offset(self._h))

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(256) void final_fwd_k(const float* __restrict__ ps,
 }
 
 // d(loss)/d(pre) for loss = 0.8*mse + 0.2*l1 over N voxels (python/training.py:147-155): c_mse = 1.6/N, c_l1 = 0.2/N
+// dpre4 (optional): the same gradient in the L4 layout with the 128 voxels of an output slab as "channels" ([tile][4 slabs][32 quads][32][4]):
+// the operand layout of the folded tail's data and weight gradients (vq_train_tail.h)
 __global__ __launch_bounds__(256) void loss_grad_k(const float* __restrict__ x, const float* __restrict__ recon, float* __restrict__ dpre, float c_mse,
-                                                   float c_l1, int64_t n_leaves, int n_tiles)
+                                                   float c_l1, int64_t n_leaves, int n_tiles, float* __restrict__ dpre4 = nullptr)
 {
     const int64_t total = (int64_t)n_tiles * 512 * 32;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -177,6 +179,10 @@ __global__ __launch_bounds__(256) void loss_grad_k(const float* __restrict__ x, 
             g = (c_mse * d + (d > 0.0f ? c_l1 : (d < 0.0f ? -c_l1 : 0.0f))) * (r * (1.0f - r));
         }
         dpre[t] = g;
+        if (dpre4) {
+            const int v = (int)((t >> 5) & 511);
+            dpre4[((((t >> 14) * 128) + (v >> 2)) * 32 + (t & 31)) * 4 + (v & 3)] = g;
+        }
     }
 }
 // sums of (recon-x)^2 and |recon-x| over the real leaves in the tile layout: partials per block, ordered reduce by the caller

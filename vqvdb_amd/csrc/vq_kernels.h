@@ -769,6 +769,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 // weights and activations of two consecutive positions live in two register sets, each refilled for position p+2 right after
 // its last MFMA has issued (64-leaf decode: the LDS-window variant spent 3 us per 0.85 us of MFMAs).
 // ------------------------------------------------------------------------------------------
+// TILEOUT (training forward): the sigmoid output goes to the position-major tile layout [tile][512][32] instead of the caller's [n][512].
+template <bool TILEOUT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void tail_small_k(ConvArgs A)   // 2 waves/SIMD: room for both register sets
 {
     constexpr int CIN = 64, NU = 8, NMT = 4, NPI = 64;
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     const f32x4* bf4 = (const f32x4*)A.bias_frag;
     const int64_t leaf = (int64_t)tile * 32 + j;
-    if (leaf >= A.n_leaves) return;
+    if (!TILEOUT && leaf >= A.n_leaves) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 bias = bf4[(d * NMT + mb) * 8 + q * 4 + g];
@@ -830,7 +832,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         sg.y = vq_sigmoid(acc[4 * g + 1] + bias.y);
         sg.z = vq_sigmoid(acc[4 * g + 2] + bias.z);
         sg.w = vq_sigmoid(acc[4 * g + 3] + bias.w);
-        *(f32x4*)(A.out + leaf * 512 + d * 128 + 32 * mb + 8 * g + 4 * q) = sg;   // 4 consecutive voxels of this lane's leaf
+        if (TILEOUT) {
+            float* o = A.out + ((size_t)tile * 512 + d * 128 + 32 * mb + 8 * g + 4 * q) * 32 + j;
+            o[0] = sg.x, o[32] = sg.y, o[64] = sg.z, o[96] = sg.w;
+        } else {
+            *(f32x4*)(A.out + leaf * 512 + d * 128 + 32 * mb + 8 * g + 4 * q) = sg;   // 4 consecutive voxels of this lane's leaf
+        }
     }
 }
 

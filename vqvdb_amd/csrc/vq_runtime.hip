@@ -29,6 +29,7 @@
 #include "vq_conv8_lds.h"
 #include "vq_train_kernels.h"
 #include "vq_grad_kernels.h"
+#include "vq_train_tail.h"
 
 namespace {
 
@@ -134,6 +135,7 @@ struct vqhip_codec {
     char* ft_part = nullptr;                                       // partial-gradient scratch
     size_t ft_part_bytes = 0;
     bool full_training = false, keep_y1 = false, weights_stale = false;
+    bool train_folded_tail = true;   // training step: up_conv + PixelShuffle3D + final as one folded operator (vq_train_tail.h); VQHIP_TRAIN_TAIL=unfolded keeps the layer-by-layer tail
     float* z4_out = nullptr;   // set around encode_chunk by the training forward: latent also in the L4 layout
     char* tr_part = nullptr;   // per-(code, row segment) partial statistics
     size_t tr_part_bytes = 0;
@@ -1098,7 +1100,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
         A.se_gate = a["gate"];   // computed once per tile by dec_csum_x6
-        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small_k, dim3(nt, 4), dim3(256), 0, s, A); });
+        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small_k<false>, dim3(nt, 4), dim3(256), 0, s, A); });
     }
     return L.rc;
 }
@@ -1464,6 +1466,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->err = "hipStreamCreate failed";
         return bail(VQHIP_ERR_DEVICE);
