@@ -362,35 +362,64 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
 #pragma unroll
     for (int b = 0; b < (SMALL ? COUT / 16 : 1); ++b) acc16[b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
-    for (int tile = t0; tile < t1; ++tile) {
-        for (int si = s0; si < s1; si += NS) {
-            __syncthreads();              // previous iteration's MFMAs have read the blocks
-            for (int i = threadIdx.x; i < NS * (COUT / 4) * 32; i += NT) {
-                const int sub = i / ((COUT / 4) * 32), quad = (i >> 5) % (COUT / 4), leaf = i & 31;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};   // a short last batch contributes zeros
-                if (si + sub < s1) v = ((const f32x4*)A.dy)[(((size_t)tile * NPO + A.wsteps[si + sub].y) * (COUT / 4) + quad) * 32 + leaf];
-                float* d = &sdy[sub * ROWS_DY + 4 * quad][leaf];
-                d[0] = v.x, d[33] = v.y, d[66] = v.z, d[99] = v.w;
-            }
-            for (int i = threadIdx.x; i < NS * (CIN / 4) * 32; i += NT) {
-                const int sub = i / ((CIN / 4) * 32), quad = (i >> 5) % (CIN / 4), leaf = i & 31;
-                const int2 e = A.wsteps[si + sub < s1 ? si + sub : s1 - 1];  // x = input position, y = output position
-                const f32x4 v = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + quad) * 32 + leaf];
-                float o[4] = {v.x, v.y, v.z, v.w};
+    // One step = one (tile, position pair).  The step's dY / X blocks are requested one step AHEAD into registers (round 2): the loads
+    // of step k+1 are in flight while step k's MFMAs run; before, every step exposed a full L2 round trip between its two barriers.
+    static_assert(NS == 1, "one position pair per step");
+    constexpr int ND = ((COUT / 4) * 32 + NT - 1) / NT, NX = ((CIN / 4) * 32 + NT - 1) / NT;
+    const int npairs = s1 - s0, nsteps = (t1 - t0) * npairs;
+    f32x4 rdy[ND], rx[NX];
+    auto fetch = [&](int k) {
+        const int tile = t0 + k / npairs;
+        const int2 e = A.wsteps[s0 + k % npairs];   // x = input position, y = output position
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ch = 4 * quad + k;
-                    if (INMODE == 1) {
-                        const int g = ch / CPG;
-                        const float ia = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
-                        const float ibb = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], ia, A.beta[ch]);
-                        o[k] = fmaxf(__builtin_fmaf(o[k], ia, ibb), 0.0f);
-                    } else if (INMODE == 2) {
-                        o[k] = o[k] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
-                    }
-                    sx[sub * ROWS_X + ch][leaf] = o[k];
+        for (int d = 0; d < ND; ++d) {
+            const int i = threadIdx.x + d * NT;
+            if (i < (COUT / 4) * 32) rdy[d] = ((const f32x4*)A.dy)[(((size_t)tile * NPO + e.y) * (COUT / 4) + (i >> 5)) * 32 + (i & 31)];
+        }
+#pragma unroll
+        for (int d = 0; d < NX; ++d) {
+            const int i = threadIdx.x + d * NT;
+            if (i < (CIN / 4) * 32) rx[d] = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + (i >> 5)) * 32 + (i & 31)];
+        }
+    };
+    if (nsteps > 0) fetch(0);
+    for (int k = 0; k < nsteps; ++k) {
+        {
+            const int tile = t0 + k / npairs;
+            __syncthreads();              // previous iteration's MFMAs have read the blocks
+#pragma unroll
+            for (int dd = 0; dd < ND; ++dd) {
+                const int i = threadIdx.x + dd * NT;
+                if (i < (COUT / 4) * 32) {
+                    const int quad = i >> 5, leaf = i & 31;
+                    const f32x4 v = rdy[dd];
+                    float* d = &sdy[4 * quad][leaf];
+                    d[0] = v.x, d[33] = v.y, d[66] = v.z, d[99] = v.w;
                 }
             }
+#pragma unroll
+            for (int dd = 0; dd < NX; ++dd) {
+                const int i = threadIdx.x + dd * NT;
+                if (i < (CIN / 4) * 32) {
+                    const int quad = i >> 5, leaf = i & 31;
+                    const f32x4 v = rx[dd];
+                    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int ch = 4 * quad + kk;
+                        if (INMODE == 1) {
+                            const int g = ch / CPG;
+                            const float ia = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
+                            const float ibb = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], ia, A.beta[ch]);
+                            o[kk] = fmaxf(__builtin_fmaf(o[kk], ia, ibb), 0.0f);
+                        } else if (INMODE == 2) {
+                            o[kk] = o[kk] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
+                        }
+                        sx[ch][leaf] = o[kk];
+                    }
+                }
+            }
+            if (k + 1 < nsteps) fetch(k + 1);   // in flight during this step's MFMAs
             __syncthreads();
             if (SMALL) {
 #pragma unroll
