@@ -345,10 +345,14 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     constexpr int CB = SMALL ? 1 : (COUT + 31) / 32, IB = SMALL ? 1 : (CIN + 31) / 32, NT = CB * IB * 64;
     constexpr int ROWS_DY = SMALL ? COUT : CB * 32, ROWS_X = SMALL ? 16 : IB * 32;
     constexpr int NS = 1;   // position pairs staged per barrier (4 for the 16-channel layers was measured 2x SLOWER than 1)
-    __shared__ float sdy[NS * ROWS_DY][33];
-    __shared__ float sx[NS * ROWS_X][33];
-    for (int i = threadIdx.x; i < NS * ROWS_DY * 33; i += NT) (&sdy[0][0])[i] = 0.0f;
-    for (int i = threadIdx.x; i < NS * ROWS_X * 33; i += NT) (&sx[0][0])[i] = 0.0f;
+    // blocks in LDS as [leaf][channel] (round 2; [channel][leaf] before): a thread's float4 = 4 channels of one leaf goes in with ONE
+    // 16-byte write instead of four scalar ones; the MFMA operands A[row = channel][k = leaf] are read row-wise over the channels
+    // (consecutive banks).  Row stride +4 floats: the 32 leaves of a write land on 8 bank groups instead of one.
+    constexpr int SDY = ROWS_DY + 4, SX = ROWS_X + 4;
+    __shared__ __attribute__((aligned(16))) float sdy[32][SDY];
+    __shared__ __attribute__((aligned(16))) float sx[32][SX];
+    for (int i = threadIdx.x; i < 32 * SDY; i += NT) (&sdy[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < 32 * SX; i += NT) (&sx[0][0])[i] = 0.0f;
     const int tap = blockIdx.x, grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
     // the tap's (ip, po) pairs are cut into gridDim.z chunks (more workgroups for the small layers)
@@ -366,77 +370,77 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     // of step k+1 are in flight while step k's MFMAs run; before, every step exposed a full L2 round trip between its two barriers.
     static_assert(NS == 1, "one position pair per step");
     constexpr int ND = ((COUT / 4) * 32 + NT - 1) / NT, NX = ((CIN / 4) * 32 + NT - 1) / NT;
+    constexpr int PD = 1;   // prefetch distance in steps (3 measured no better: r64 layers -2 %, stem and r32 layers +10 %)
     const int npairs = s1 - s0, nsteps = (t1 - t0) * npairs;
-    f32x4 rdy[ND], rx[NX];
-    auto fetch = [&](int k) {
+    f32x4 rdy[PD][ND], rx[PD][NX];
+    auto fetch = [&](int k, f32x4 (&qdy)[ND], f32x4 (&qx)[NX]) {
+        if (k >= nsteps) return;   // (uniform)
         const int tile = t0 + k / npairs;
         const int2 e = A.wsteps[s0 + k % npairs];   // x = input position, y = output position
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int i = threadIdx.x + d * NT;
-            if (i < (COUT / 4) * 32) rdy[d] = ((const f32x4*)A.dy)[(((size_t)tile * NPO + e.y) * (COUT / 4) + (i >> 5)) * 32 + (i & 31)];
+            if (i < (COUT / 4) * 32) qdy[d] = ((const f32x4*)A.dy)[(((size_t)tile * NPO + e.y) * (COUT / 4) + (i >> 5)) * 32 + (i & 31)];
         }
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             const int i = threadIdx.x + d * NT;
-            if (i < (CIN / 4) * 32) rx[d] = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + (i >> 5)) * 32 + (i & 31)];
+            if (i < (CIN / 4) * 32) qx[d] = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + (i >> 5)) * 32 + (i & 31)];
         }
     };
-    if (nsteps > 0) fetch(0);
-    for (int k = 0; k < nsteps; ++k) {
-        {
-            const int tile = t0 + k / npairs;
-            __syncthreads();              // previous iteration's MFMAs have read the blocks
+    // one step: blocks of step k (in registers) -> LDS ([leaf][channel], GroupNorm+ReLU / gate applied to X on the way), request step
+    // k + PD into the registers just freed, MFMAs
+    auto step = [&](int k, f32x4 (&qdy)[ND], f32x4 (&qx)[NX]) {
+        const int tile = t0 + k / npairs;
+        __syncthreads();              // previous step's MFMAs have read the blocks
 #pragma unroll
-            for (int dd = 0; dd < ND; ++dd) {
-                const int i = threadIdx.x + dd * NT;
-                if (i < (COUT / 4) * 32) {
-                    const int quad = i >> 5, leaf = i & 31;
-                    const f32x4 v = rdy[dd];
-                    float* d = &sdy[4 * quad][leaf];
-                    d[0] = v.x, d[33] = v.y, d[66] = v.z, d[99] = v.w;
-                }
-            }
+        for (int dd = 0; dd < ND; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (COUT / 4) * 32) *(f32x4*)&sdy[i & 31][4 * (i >> 5)] = qdy[dd];
+        }
 #pragma unroll
-            for (int dd = 0; dd < NX; ++dd) {
-                const int i = threadIdx.x + dd * NT;
-                if (i < (CIN / 4) * 32) {
-                    const int quad = i >> 5, leaf = i & 31;
-                    const f32x4 v = rx[dd];
-                    float o[4] = {v.x, v.y, v.z, v.w};
+        for (int dd = 0; dd < NX; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (CIN / 4) * 32) {
+                const int quad = i >> 5, leaf = i & 31;
+                const f32x4 v = qx[dd];
+                float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int ch = 4 * quad + kk;
-                        if (INMODE == 1) {
-                            const int g = ch / CPG;
-                            const float ia = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
-                            const float ibb = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], ia, A.beta[ch]);
-                            o[kk] = fmaxf(__builtin_fmaf(o[kk], ia, ibb), 0.0f);
-                        } else if (INMODE == 2) {
-                            o[kk] = o[kk] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
-                        }
-                        sx[ch][leaf] = o[kk];
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = 4 * quad + kk;
+                    if (INMODE == 1) {
+                        const int g = ch / CPG;
+                        const float ia = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
+                        const float ibb = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], ia, A.beta[ch]);
+                        o[kk] = fmaxf(__builtin_fmaf(o[kk], ia, ibb), 0.0f);
+                    } else if (INMODE == 2) {
+                        o[kk] = o[kk] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
                     }
                 }
-            }
-            if (k + 1 < nsteps) fetch(k + 1);   // in flight during this step's MFMAs
-            __syncthreads();
-            if (SMALL) {
-#pragma unroll
-                for (int sub = 0; sub < NS; ++sub)
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        const float bx = sx[sub * ROWS_X + (lane & 15)][4 * m + (lane >> 4)];
-#pragma unroll
-                        for (int b = 0; b < COUT / 16; ++b)
-                            acc16[b] = mfma16(sdy[sub * ROWS_DY + 16 * b + (lane & 15)][4 * m + (lane >> 4)], bx, acc16[b]);
-                    }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 16; ++m)
-                    acc = mfma32(sdy[32 * cb + (lane & 31)][2 * m + (lane >> 5)], sx[32 * ib + (lane & 31)][2 * m + (lane >> 5)], acc);
+                *(f32x4*)&sx[leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
             }
         }
+        fetch(k + PD, qdy, qx);   // in flight during the next PD steps' MFMAs
+        __syncthreads();
+        if (SMALL) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float bx = sx[4 * m + (lane >> 4)][lane & 15];
+#pragma unroll
+                for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[4 * m + (lane >> 4)][16 * b + (lane & 15)], bx, acc16[b]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                acc = mfma32(sdy[2 * m + (lane >> 5)][32 * cb + (lane & 31)], sx[2 * m + (lane >> 5)][32 * ib + (lane & 31)], acc);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < PD; ++r) fetch(r, rdy[r], rx[r]);
+    for (int k = 0; k < nsteps; k += PD) {   // the register sets rotate with a static index
+#pragma unroll
+        for (int r = 0; r < PD; ++r)
+            if (k + r < nsteps) step(k + r, rdy[r], rx[r]);
     }
     float* dst = A.part + (((size_t)grp * gridDim.z + blockIdx.z) * A.KT + tap) * COUT * CIN;
     if (SMALL) {
