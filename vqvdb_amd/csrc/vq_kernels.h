@@ -71,6 +71,24 @@ __device__ __forceinline__ void glds16(const f32x4* gsrc_lane, f32x4* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS reads the compiler does not see as LDS reads.  Behind a global_load_lds the compiler puts "s_waitcnt vmcnt(<= that copy)" in
+// front of EVERY ordinary LDS load that follows (it cannot tell the window being filled from the one being read), so a kernel that
+// streams the next step's weights while it reads this step's would begin each step by waiting for the copy it has just started.
+// The kernels below order the two by hand (vmcnt + barrier at the step boundary), so the fragment reads go through these:
+// lds_frag_read issues, lds_frags_wait() + lds_frag_use() in front of the first use make the data dependence visible again.
+__device__ __forceinline__ unsigned lds_offset_of(const void* p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ f32x4 lds_frag_read(unsigned byte_addr)
+{
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+__device__ __forceinline__ void lds_frags_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_frag_use(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 // ------------------------------------------------------------------------------------------
 // pack: host/leaf-major leaves [n][512] (VQVAECodec.cpp:36-59 layout in) ->
 //   xr[tile][row 64][leaf 32][12]   the first conv's input: one W-row of a leaf = (0, x0 .. x7, 0, -, -), halo zeros included, so
@@ -858,7 +876,7 @@ template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int IN
 __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     // ABL: timing-only ablations for tools/ablate/conv_rows16_ablate.hip (0 in the library): 1 no barriers, 2 no weight streaming,
-    // 4 no LDS A-fragment reads, 8 no activation re-loads, 16 no GroupNorm transform, 32 no epilogue
+    // 4 no LDS A-fragment reads, 8 no activation re-loads, 16 no GroupNorm transform, 32 no epilogue, 64 every tile reads tile 0 (L2 hits)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int CBN = CIN / 16, MTN = COUT / 16, NPI = SI * SI * SI, NPO = SO * SO * SO;
@@ -866,6 +884,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     // MSPLIT > 1 (small batches): blockIdx.z selects MTL of the MTN 16-cout blocks, so a wave's serial MFMA chain is MSPLIT times
     // shorter; the K order of every output is unchanged.  Only the needed weight pieces are staged, packed densely in LDS.
     constexpr int MTL = MTN / MSPLIT, WTAPL = WTAP / MSPLIT, WSTEPL = WSTEP / MSPLIT;
+    // REGW: the next step's weight pieces travel global -> register -> LDS, one piece per MFMA group, instead of by global_load_lds.
+    // The async copy looks cheaper (no registers, no ds_write) but costs a stall per step: while one is in flight the compiler answers
+    // EVERY vector-memory dependence with s_waitcnt vmcnt(0) (a pending LDS-DMA counts as a flat access that may complete out of order),
+    // so the first use of a re-loaded input position waited for the weight copy requested a few instructions earlier — one L2 round
+    // trip per step with the matrix pipe idle, for both waves of a SIMD at once.  With plain loads every wait is an exact count.
+    constexpr int NPCW = (WSTEPL / 64) / NWV;                    // weight pieces (1 KiB) per wave and step
+    constexpr bool REGW = KWO && !RESIDENT && (WSTEPL / 64) % NWV == 0 && !(ABL & 2);
+    constexpr bool APF = REGW && !(ABL & 128);                   // A fragments read one group ahead (ABL 128: at the group's start)
+    constexpr int CPW = APF ? 1 : (CBN % 2 == 0 ? 2 : 1);        // channel blocks per kw-outer MFMA group
+    constexpr int NGRP = KS * (CBN / CPW);                       // MFMA groups per step
+    constexpr int PPG = REGW ? (NPCW + NGRP - 1) / NGRP : 1;     // most pieces any group carries
+    auto regw_first = [](int g) { return (g * NPCW + NGRP - 1) / NGRP; };   // first piece of group g: piece k travels with group floor(k*NGRP/NPCW)
     static_assert(MTN % MSPLIT == 0 && (MSPLIT == 1 || PARTS || (GOUT == 0 && !CSUM)), "cout split: statistics only as per-block partials");
     const int mz = MSPLIT > 1 ? blockIdx.z * MTL : 0;
     static_assert(INMODE == 0 || INMODE == 1, "raw or GroupNorm(8)+ReLU input");
@@ -883,6 +913,26 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     // 7 % slower — 1.58 vs 1.47 ms)
     // The per-half-tile body is a lambda called once.  That is deliberate: with the body inline the compiler schedules the down conv's
     // two-step prefetch loop worse (enc_down 1.54 ms inline, 1.47 ms as a lambda; every other instantiation unchanged) — measured, kept.
+    // one step's weight pieces (KS taps) into LDS window `slot`, 1 KiB per wave-instruction.  A fixed number of instructions per wave
+    // where the pieces divide evenly: behind a loop with a run-time trip count the compiler cannot count the outstanding loads and
+    // puts s_waitcnt vmcnt(0) in front of the first use of ANY loaded register, i.e. waits for the pieces it has just requested.
+    auto stream_weights = [&](int tap0, int slot) {
+        constexpr int NPC = WSTEPL / 64;
+        if (NPC % NWV == 0) {
+#pragma unroll
+            for (int k = 0; k < NPC / NWV; ++k) {
+                const int t = wave + k * NWV;
+                const int piece = (t / MTL) * MTN + mz + t % MTL;
+                glds16(wg4 + (size_t)tap0 * WTAP + piece * 64 + lane, lds + slot * WSTEPL + t * 64);
+            }
+        } else {
+            for (int t = wave; t < NPC; t += NWV) {
+                const int piece = (t / MTL) * MTN + mz + t % MTL;
+                glds16(wg4 + (size_t)tap0 * WTAP + piece * 64 + lane, lds + slot * WSTEPL + t * 64);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto process = [&](int half) {   // NWV half tiles per workgroup (16 for LDS-resident weights: 4 waves/SIMD behind one copy)
     const bool active = (half >> 1) < A.n_tiles;
     // waves past the last half tile only help staging the weights; in the launches without fused statistics (small batches: a
@@ -912,7 +962,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     f32x4 cs[CSUM ? MTN : 1], csb[CSUM ? MTN : 1];   // channel sums: closed blocks / open block (same 16-block rule, fp32)
 #pragma unroll
     for (int k = 0; k < (CSUM ? MTN : 1); ++k) cs[k] = csb[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q4 * 32 + jj;   // + (pos*(CIN/4) + 4cb)*32
+    // input position `pos`, channel block cb of this lane: wave-uniform 64-bit base + 32-bit lane offset, so that the load takes the
+    // scalar-base form (one address register per lane instead of a 64-bit pair, no per-row 64-bit vector add)
+    const f32x4* in_u = (const f32x4*)A.in + (size_t)((ABL & 64) ? 0 : tile) * NPI * (CIN / 4) * 32;
+    const unsigned lane_b = (unsigned)(q4 * 32 + jj) * 16u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)in_u, 0, 0x7fffffff, 0x00020000);
+    auto ldx = [&](int pos, int cb) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_b + cb * 2048, pos * (CIN / 4) * 512, 0));
+    };
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj;
     const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj : nullptr;
     const f32x4* bias4 = (const f32x4*)A.bias_frag;   // plain [COUT]: quad 4mt + q4
@@ -924,19 +981,39 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
     f32x4 xr[SI][CBN];
     f32x4 xq[PF2 ? SI : 1][PF2 ? CBN : 1];   // PF2: the row of step+1 waits here while the row of step+2 is in flight
+    // Streamed weights: the pieces of a step are requested BEFORE the input positions of the same step, here and in the loop, so that
+    // "all but the last NLD vector-memory operations have completed" (s_waitcnt vmcnt(NLD), loads return in order) means "my weight
+    // pieces have landed" without also waiting for the positions re-loaded at the end of the previous step.
+    if (REGW) {
+#pragma unroll
+        for (int k = 0; k < NPCW; ++k) {
+            const int t = wave + k * NWV;
+            lds[(si & 1) * WSTEPL + t * 64 + lane] = wg4[(size_t)e.y * WTAP + ((t / MTL) * MTN + mz + t % MTL) * 64 + lane];
+        }
+    } else if (!RESIDENT) {
+        stream_weights(e.y, si & 1);
+    }
 #pragma unroll
     for (int iw = 0; iw < SI; ++iw)
 #pragma unroll
         for (int cb = 0; cb < CBN; ++cb) {
-            xr[iw][cb] = in4[((size_t)(e.x + iw) * (CIN / 4) + 4 * cb) * 32];
-            if (PF2) xq[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];
+            xr[iw][cb] = ldx(e.x + iw, cb);
+            if (PF2) xq[iw][cb] = ldx(en.x + iw, cb);
         }
-    if (!RESIDENT) {
-        for (int t = wave; t < WSTEPL / 64; t += NWV) {
-            const int piece = (t / MTL) * MTN + mz + t % MTL;
-            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WSTEPL + t * 64);
-        }
-    }
+    // The first row is waited for here, in full: entering the step loop with loads in flight in an order of the compiler's choosing
+    // makes it answer the loop's own first-use dependences with the worst case of both paths, i.e. s_waitcnt vmcnt(0) in every step.
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    // GroupNorm + ReLU of one arrived position / channel block, applied right before its first MFMA of the step (not for the whole row
+    // at the top of the step: that made every step begin by waiting for the position re-loaded last, one L2 round trip with the matrix
+    // pipe idle, both waves of a SIMD at once because the barrier keeps them in step)
+    auto arrive = [&](int iw, int cb) {
+        f32x4 v = xr[iw][cb];
+        v.x = fmaxf(__builtin_fmaf(v.x, ta[cb][0], tb[cb][0]), 0.0f);
+        v.y = fmaxf(__builtin_fmaf(v.y, ta[cb][1], tb[cb][1]), 0.0f);
+        v.z = fmaxf(__builtin_fmaf(v.z, ta[cb][2], tb[cb][2]), 0.0f);
+        v.w = fmaxf(__builtin_fmaf(v.w, ta[cb][3], tb[cb][3]), 0.0f);
+        xr[iw][cb] = v;
+    };
     for (int row = g0; row < g1; ++row) {
         f32x4 acc[SO][MTL];
 #pragma unroll
@@ -945,63 +1022,129 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         bool last;
         do {
-            if (INMODE == 1 && work && !(ABL & 16)) {   // first use of the rolling buffer: waits for the loads (and weight pieces) of the previous step
-#pragma unroll
-                for (int iw = 0; iw < SI; ++iw)
-#pragma unroll
-                    for (int cb = 0; cb < CBN; ++cb) {
-                        f32x4 v = xr[iw][cb];
-                        v.x = fmaxf(__builtin_fmaf(v.x, ta[cb][0], tb[cb][0]), 0.0f);
-                        v.y = fmaxf(__builtin_fmaf(v.y, ta[cb][1], tb[cb][1]), 0.0f);
-                        v.z = fmaxf(__builtin_fmaf(v.z, ta[cb][2], tb[cb][2]), 0.0f);
-                        v.w = fmaxf(__builtin_fmaf(v.w, ta[cb][3], tb[cb][3]), 0.0f);
-                        xr[iw][cb] = v;
-                    }
-            }
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];
-            if (!RESIDENT) {
-                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight pieces and input row have landed
+            if (REGW) {
+                if (!(ABL & 1)) __syncthreads();      // every wave's pieces of W(step) are in LDS; every wave done reading W(step-1)
+            } else if (!RESIDENT) {
+                // this wave's weight pieces have landed: everything but the NLD position loads a working wave has issued since
+                constexpr int NLD = (PF2 || (ABL & 8)) ? 0 : SI * CBN;
+                static_assert(NLD < 64, "vmcnt is a 6-bit counter");
+                if (work) __builtin_amdgcn_s_waitcnt(0x0f70 | (NLD & 15) | ((NLD >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt(0x0f70);
                 if (!(ABL & 1)) __syncthreads();      // every wave's pieces of W(step) landed; every wave done reading W(step-1)
-                f32x4* dst = lds + ((si + 1) & 1) * WSTEPL;
-                for (int t = wave; t < ((ABL & 2) ? 0 : WSTEPL / 64); t += NWV) {
-                    const int piece = (t / MTL) * MTN + mz + t % MTL;
-                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + t * 64);
-                }
+                if (!(ABL & 2)) stream_weights(en.y, (si + 1) & 1);   // requested before any position of this step (see NLD)
             }
             const f32x4* wl = (RESIDENT ? lds + (size_t)e.y * WTAPL : lds + (si & 1) * WSTEPL) + lane;
             if (KWO) {
-                // kw-outer order: the A fragments of one (kw, pair of channel blocks) are read once from LDS and feed every output of the
-                // row that has this kw (3-4 outputs x 2 blocks x MTL x 4 MFMAs per 2*MTL ds_read_b128, instead of one block's MTL x 4).
+                // kw-outer order: the A fragments of one (kw, group of channel blocks) are read once from LDS and feed every output of the
+                // row that has this kw (3-4 outputs x CP blocks x MTL x 4 MFMAs per CP*MTL ds_read_b128, instead of one block's MTL x 4).
                 // Per output the taps still arrive with kw ascending and, inside a tap, the channel blocks ascending: same arithmetic.
                 static_assert(!KWO || !PF2, "kw-outer: single rolling buffer");
-                constexpr int CP = CBN % 2 == 0 ? 2 : 1;   // channel blocks per A-fragment group
+                constexpr int CP = CPW, NG = NGRP;
                 if (work) {
-#pragma unroll
-                    for (int kw = 0; kw < KS; ++kw) {
-#pragma unroll
-                        for (int cbp = 0; cbp < CBN; cbp += CP) {
-                            f32x4 a[CP][MTL];
+                    // APF: the fragments of group g+1 are read while group g computes (two sets of CP*MTL registers).  All eight waves reach
+                    // a group boundary together (the barrier keeps them in step), so reads issued AT the boundary queue behind each other
+                    // on the one LDS port with the matrix pipe idle; issued a group ahead nobody waits for them.
+                    f32x4 a[APF ? 2 : 1][CP][MTL];
+                    auto read_group = [&](int g, int set) {
+                        const int kw = g / (CBN / CP), cbp = (g % (CBN / CP)) * CP;
+                        if (!RESIDENT && !REGW) {   // window filled by global_load_lds: hand-ordered reads (see lds_frag_read)
+                            const unsigned wa = lds_offset_of(wl);
 #pragma unroll
                             for (int c2 = 0; c2 < CP; ++c2)
 #pragma unroll
-                                for (int mt = 0; mt < MTL; ++mt) a[c2][mt] = wl[((kw * CBN + cbp + c2) * MTL + mt) * 64];
+                                for (int mt = 0; mt < MTL; ++mt) a[set][c2][mt] = lds_frag_read(wa + ((kw * CBN + cbp + c2) * MTL + mt) * 1024);
+                            lds_frags_wait();
 #pragma unroll
-                            for (int ow = 0; ow < SO; ++ow) {
-                                const int iw = ow * STRIDE - PAD + kw;
-                                if (iw < 0 || iw >= SI) continue;
+                            for (int c2 = 0; c2 < CP; ++c2)
+#pragma unroll
+                                for (int mt = 0; mt < MTL; ++mt) lds_frag_use(a[set][c2][mt]);
+                        } else {
+#pragma unroll
+                            for (int c2 = 0; c2 < CP; ++c2)
+#pragma unroll
+                                for (int mt = 0; mt < MTL; ++mt) a[set][c2][mt] = wl[((kw * CBN + cbp + c2) * MTL + mt) * 64];
+                        }
+                    };
+                    if (APF) read_group(0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const int kw = g / (CBN / CP), cbp = (g % (CBN / CP)) * CP, set = APF ? (g & 1) : 0;
+                        if (INMODE == 1 && !(ABL & 16)) {   // positions whose first tap of the row is this kw arrive here
+#pragma unroll
+                            for (int iw = 0; iw < SI; ++iw) {
+                                int firstkw = -1;
+#pragma unroll
+                                for (int k2 = KS - 1; k2 >= 0; --k2) {
+                                    const int num = iw + PAD - k2;
+                                    if (num >= 0 && num % STRIDE == 0 && num / STRIDE < SO) firstkw = k2;
+                                }
+                                if (firstkw == kw) {
+#pragma unroll
+                                    for (int c2 = 0; c2 < CP; ++c2) arrive(iw, cbp + c2);
+                                }
+                            }
+                        }
+                        // REGW: piece k of this wave's NPCW travels with group k*NG/NPCW (requested here, stored after the group's MFMAs)
+                        f32x4 wnext[PPG];
+                        if (REGW) {
+#pragma unroll
+                            for (int j = 0; j < PPG; ++j) {
+                                const int k = regw_first(g) + j;
+                                if (k < regw_first(g + 1)) {
+                                    const int t = wave + k * NWV;
+                                    wnext[j] = wg4[(size_t)en.y * WTAP + ((t / MTL) * MTN + mz + t % MTL) * 64 + lane];
+                                }
+                            }
+                        }
+                        if (APF) {
+                            if (g + 1 < NG) read_group(g + 1, set ^ 1);
+                        } else {
+                            read_group(g, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // requests first, a whole group ahead of their use (not sunk next to it)
+#pragma unroll
+                        for (int ow = 0; ow < SO; ++ow) {
+                            const int iw = ow * STRIDE - PAD + kw;
+                            if (iw < 0 || iw >= SI) continue;
+                            // k outer, cout tile inner: consecutive MFMAs go to different accumulators (each accumulator still sees its
+                            // k steps in ascending order), so neither the dependent-issue latency nor an instruction the scheduler
+                            // drops between two of them lands between an MFMA and the one that needs its result
+#pragma unroll
+                            for (int c2 = 0; c2 < CP; ++c2)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                    for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = mfma16(a[set][c2][mt][k], xr[iw][cbp + c2][k], acc[ow][mt]);
+                            // was this kw the position's last tap of the row?  Then these channel blocks are re-loaded for the next step
+                            // right here, between the outputs' MFMA runs (not all of a group's re-loads in one burst at its end: the
+                            // eight waves of a workgroup run in step, and a burst of requests stalls their issue)
+                            int lastkw = -1;
+#pragma unroll
+                            for (int k2 = 0; k2 < KS; ++k2) {
+                                const int num = iw + PAD - k2;
+                                if (num >= 0 && num % STRIDE == 0 && num / STRIDE < SO) lastkw = k2;
+                            }
+                            if (lastkw == kw && !(ABL & 8)) {
+                                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                                 for (int c2 = 0; c2 < CP; ++c2)
-#pragma unroll
-                                    for (int mt = 0; mt < MTL; ++mt) {
-                                        acc[ow][mt] = mfma16(a[c2][mt].x, xr[iw][cbp + c2].x, acc[ow][mt]);
-                                        acc[ow][mt] = mfma16(a[c2][mt].y, xr[iw][cbp + c2].y, acc[ow][mt]);
-                                        acc[ow][mt] = mfma16(a[c2][mt].z, xr[iw][cbp + c2].z, acc[ow][mt]);
-                                        acc[ow][mt] = mfma16(a[c2][mt].w, xr[iw][cbp + c2].w, acc[ow][mt]);
-                                    }
+                                    xr[iw][cbp + c2] = ldx(en.x + iw, (cbp + c2));   // next step's row (index clamped)
+                                __builtin_amdgcn_sched_barrier(0);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        // positions whose last tap of the row was this kw: re-load for the next step
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (REGW) {
+#pragma unroll
+                            for (int j = 0; j < PPG; ++j) {
+                                const int k = regw_first(g) + j;
+                                if (k < regw_first(g + 1)) {
+                                    const int t = wave + k * NWV;
+                                    lds[((si + 1) & 1) * WSTEPL + t * 64 + lane] = wnext[j];
+                                }
+                            }
+                        }
+                        // positions no output of the row reads (strided layers) still follow the rolling buffer
 #pragma unroll
                         for (int iw = 0; iw < SI; ++iw) {
                             int lastkw = -1;
@@ -1010,18 +1153,33 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                                 const int num = iw + PAD - k2;
                                 if (num >= 0 && num % STRIDE == 0 && num / STRIDE < SO) lastkw = k2;
                             }
-                            if (lastkw == kw || (lastkw < 0 && kw == 0)) {
+                            if (lastkw < 0 && kw == 0) {
 #pragma unroll
-                                for (int cb = 0; cb < CBN; ++cb)
-                                    if (!(ABL & 8)) xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
+                                for (int c2 = 0; c2 < CP; ++c2)
+                                    if (!(ABL & 8)) xr[iw][cbp + c2] = ldx(en.x + iw, (cbp + c2));   // next step's row (index clamped)
                             }
                         }
+                    }
+                } else if (REGW) {   // a wave without a half tile still carries its share of the weights
+#pragma unroll
+                    for (int k = 0; k < NPCW; ++k) {
+                        const int t = wave + k * NWV;
+                        lds[((si + 1) & 1) * WSTEPL + t * 64 + lane] = wg4[(size_t)en.y * WTAP + ((t / MTL) * MTN + mz + t % MTL) * 64 + lane];
                     }
                 }
             } else
             if (work)
 #pragma unroll
             for (int iw = 0; iw < SI; ++iw) {
+                if (INMODE == 1 && !(ABL & 16)) {
+                    bool used = false;
+#pragma unroll
+                    for (int ow = 0; ow < SO; ++ow) used = used || (iw - ow * STRIDE + PAD >= 0 && iw - ow * STRIDE + PAD < KS);
+                    if (used) {
+#pragma unroll
+                        for (int cb = 0; cb < CBN; ++cb) arrive(iw, cb);
+                    }
+                }
 #pragma unroll
                 for (int ow = 0; ow < SO; ++ow) {
                     const int kw = iw - ow * STRIDE + PAD;
@@ -1029,8 +1187,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
 #pragma unroll
                     for (int cb = 0; cb < CBN; ++cb) {
                         f32x4 a[MTL];   // the cout tiles of this (tap, channel block): MTN LDS reads ahead of their MFMAs, no further
+                        if (!RESIDENT && !(ABL & 4)) {   // streamed window: hand-ordered reads (see lds_frag_read)
+                            const unsigned wa = lds_offset_of(wl);
+#pragma unroll
+                            for (int mt = 0; mt < MTL; ++mt) a[mt] = lds_frag_read(wa + ((kw * CBN + cb) * MTL + mt) * 1024);
+                            lds_frags_wait();
+#pragma unroll
+                            for (int mt = 0; mt < MTL; ++mt) lds_frag_use(a[mt]);
+                        } else {
 #pragma unroll
                         for (int mt = 0; mt < MTL; ++mt) a[mt] = (ABL & 4) ? xr[(iw + mt) % SI][cb] : wl[((kw * CBN + cb) * MTL + mt) * 64];
+                        }
 #pragma unroll
                         for (int mt = 0; mt < MTL; ++mt) {
                             acc[ow][mt] = mfma16(a[mt].x, xr[iw][cb].x, acc[ow][mt]);
@@ -1045,9 +1212,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                 for (int cb = 0; cb < CBN; ++cb) {
                     if (PF2) {
                         xr[iw][cb] = xq[iw][cb];
-                        xq[iw][cb] = in4[((size_t)(en2.x + iw) * (CIN / 4) + 4 * cb) * 32];   // the row after next (index clamped)
+                        xq[iw][cb] = ldx(en2.x + iw, cb);   // the row after next (index clamped)
                     } else if (!(ABL & 8)) {
-                        xr[iw][cb] = in4[((size_t)(en.x + iw) * (CIN / 4) + 4 * cb) * 32];   // next step's row (index clamped)
+                        xr[iw][cb] = ldx(en.x + iw, cb);   // next step's row (index clamped)
                     }
                 }
             }
@@ -1066,6 +1233,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             if (t == 12345.678f) out4[0] = acc[0][0];
             continue;
         }
+        f32x4 bq[MTL];   // this lane's bias quads, once per row (left in the expression below they are re-loaded for every position,
+#pragma unroll           // each load followed by s_waitcnt vmcnt(0): the stores in between may alias as far as the compiler knows)
+        for (int mt = 0; mt < MTL; ++mt) bq[mt] = bias4[4 * (mz + mt) + q4];
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow) {
             const size_t o = ((size_t)(row * SO + ow) * (COUT / 4)) * 32;
@@ -1076,7 +1246,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             }
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt) {
-                f32x4 v = acc[ow][mt] + bias4[4 * (mz + mt) + q4];
+                f32x4 v = acc[ow][mt] + bq[mt];
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
                     v = sk[mt] + u;
