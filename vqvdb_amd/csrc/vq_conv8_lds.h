@@ -59,6 +59,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
     // border half row (2 of 3 kh taps) and three inner ones — equal MFMA work per SIMD between barriers.  As a loader a wave
     // brings in OWN consecutive input positions of every plane.
     const int oh = NW == 8 ? wave : wave >> 1, ow0 = NW == 8 ? 0 : (wave & 1) * 4;
+    const unsigned lane_b = (unsigned)(q4 * 32 + j16) * 16u;   // this lane inside a [pos][4 q4][32 leaves] float4 position (see buf_ld16)
 
     // ---- plane prefetch: LPOS positions per loading wave, this lane's channel quad, + the GroupNorm statistics of that half tile ----
     // LD2: only the two border-row waves (rows 0 and 7 have 2 of the 3 kh taps: a third less MFMA work) stage the planes, 32
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
         if (!loader) return;   // (wave-uniform)
         const int hh = (int)blockIdx.x + (P >> 3) * (int)gridDim.x, id = P & 7;
         const int tile = hh >> 1, jj = j16 + 16 * (hh & 1);
-        const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+        const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + 16 * (hh & 1));
 #pragma unroll
-        for (int k = 0; k < LPOS; ++k) pf[k] = in4[(size_t)(id * 64 + lbase + k) * 4 * 32];
+        for (int k = 0; k < LPOS; ++k) pf[k] = buf_ld16(inb, lane_b, (unsigned)(id * 64 + lbase + k) * 2048u);
         // channels 4q4 .. 4q4+3 -> GroupNorm(8,16) groups 2q4 (channels 0,1 of the quad) and 2q4+1 (channels 2,3)
         pm0 = A.in_mean[((size_t)tile * 8 + 2 * q4) * 32 + jj], pr0 = A.in_rstd[((size_t)tile * 8 + 2 * q4) * 32 + jj];
         pm1 = A.in_mean[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj], pr1 = A.in_rstd[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj];
@@ -168,9 +169,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
         }
         f32x4 sk[RESID ? OWN : 1];
         if (RESID) {   // residual input of this row, consumed in the epilogue
-            const f32x4* skip4 = (const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+            const vq_buf skb = buf_of((const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 + 16 * (hh & 1));
 #pragma unroll
-            for (int ow = 0; ow < OWN; ++ow) sk[ow] = skip4[(size_t)((od * 8 + oh) * 8 + ow0 + ow) * 4 * 32];
+            for (int ow = 0; ow < OWN; ++ow) sk[ow] = buf_ld16(skb, lane_b, (unsigned)((od * 8 + oh) * 8 + ow0 + ow) * 2048u);
         }
         taps(slots + (P & 1) * 4096, 1);
         if (!(ABL & 1)) lds_barrier();   // plane od+1 is visible
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
 
         // ---- epilogue: this wave's positions of row (od, oh), ascending ----
         f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
+        const vq_buf outb = buf_of((f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + 16 * (hh & 1));
 #pragma unroll
         for (int ow = 0; ow < OWN; ++ow) {
             f32x4 v = acc[ow] + bias4;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
                 const f32x4 u = v * 0.1f;
                 v = sk[ow] + u;
             }
-            if (!(ABL & 2)) __builtin_nontemporal_store(v, &out4[(size_t)((od * 8 + oh) * 8 + ow0 + ow) * 4 * 32]);   // streaming: read by the next kernel from HBM anyway
+            if (!(ABL & 2)) buf_st16_nt(v, outb, lane_b, (unsigned)((od * 8 + oh) * 8 + ow0 + ow) * 2048u);
             if ((ABL & 2) && ow == 0 && v.x == 12345.678f) out4[0] = v;   // keep the accumulators alive
             if (STATS && !(ABL & 2)) {
                 st[0].add(v.x);

@@ -21,6 +21,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VQ_LT 32  // leaves per tile
 
+// Buffer addressing for the activation traffic of the MFMA kernels: a wave-uniform base (descriptor in four SGPRs) + a wave-uniform
+// byte offset (one SGPR) + a per-lane byte offset that never changes (one VGPR).  The same access written as a per-lane 64-bit
+// pointer costs a 64-bit vector add per row and an address register PAIR per request, and each such global_load/global_store
+// issued into a stream of MFMAs held the matrix pipe for ~100-200 cycles (measured: the decoder's 64->64 conv went from 3.91 to
+// 3.70 ms, pure MFMA time 3.55, by this change alone).  Offsets are bytes; the range is 2 GiB from the base.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t vq_buf;
+__device__ __forceinline__ vq_buf buf_of(const void* uniform_base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_base, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld16(vq_buf b, unsigned lane_bytes, unsigned uniform_bytes)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)lane_bytes, (int)uniform_bytes, 0));
+}
+__device__ __forceinline__ float buf_ld4(vq_buf b, unsigned lane_bytes, unsigned uniform_bytes)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)lane_bytes, (int)uniform_bytes, 0));
+}
+// Stores: the uniform offset is ADDED INTO THE VECTOR OFFSET (one 32-bit add), the scalar-offset field stays 0.  With a register in
+// that field the compiler assumes the "store of more than 64 bits, then a write of its data registers" hazard does not exist and
+// drops the wait state — on gfx950 it does exist: v_pk_add_f32 into the data registers straight after buffer_store_dwordx4 ...
+// s5 offen corrupted one component of four lanes per row (caught by the bit-exact intermediate comparison of the encoder).
+__device__ __forceinline__ void buf_st16(f32x4 v, vq_buf b, unsigned lane_bytes, unsigned uniform_bytes)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, (int)(lane_bytes + uniform_bytes), 0, 0);
+}
+// streaming (non-temporal) store: the output is read next by another kernel, from HBM anyway
+__device__ __forceinline__ void buf_st16_nt(f32x4 v, vq_buf b, unsigned lane_bytes, unsigned uniform_bytes)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, (int)(lane_bytes + uniform_bytes), 0, 2);
+}
+
 // D = A(32x2) * B(2x32) + C, exact fp32 (k-ordered fmaf chain), 64 cycles/SIMD.
 // Lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
 // result reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].

@@ -966,10 +966,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     // scalar-base form (one address register per lane instead of a 64-bit pair, no per-row 64-bit vector add)
     const f32x4* in_u = (const f32x4*)A.in + (size_t)((ABL & 64) ? 0 : tile) * NPI * (CIN / 4) * 32;
     const unsigned lane_b = (unsigned)(q4 * 32 + jj) * 16u;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)in_u, 0, 0x7fffffff, 0x00020000);
-    auto ldx = [&](int pos, int cb) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_b + cb * 2048, pos * (CIN / 4) * 512, 0));
-    };
+    const vq_buf xrs = buf_of(in_u);
+    auto ldx = [&](int pos, int cb) -> f32x4 { return buf_ld16(xrs, lane_b + cb * 2048, (unsigned)pos * (CIN / 4) * 512u); };
+    const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32);
+    const vq_buf skb = buf_of(RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 : (const f32x4*)A.out);
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj;
     const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj : nullptr;
     const f32x4* bias4 = (const f32x4*)A.bias_frag;   // plain [COUT]: quad 4mt + q4
@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
             f32x4 sk[RESID ? MTL : 1];
             if (RESID) {
 #pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) sk[mt] = skip4[o + (size_t)4 * (mz + mt) * 32];
+                for (int mt = 0; mt < MTL; ++mt) sk[mt] = buf_ld16(skb, lane_b + (mz + mt) * 2048, (unsigned)(row * SO + ow) * (COUT / 4) * 512u);
             }
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt) {
@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                     const f32x4 u = v * 0.1f;
                     v = sk[mt] + u;
                 }
-                if (active) __builtin_nontemporal_store(v, &out4[o + (size_t)4 * (mz + mt) * 32]);   // streaming store (see conv_first_k)
+                if (active) buf_st16_nt(v, outb, lane_b + (mz + mt) * 2048, (unsigned)(row * SO + ow) * (COUT / 4) * 512u);   // streaming store (see conv_first_k)
                 if (GOUT > 0) {
                     st[mt].add(v.x);
                     st[mt].add(v.y);
