@@ -549,22 +549,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
+    static_assert(STREAM, "every instantiation streams its weights (the LDS-resident variant went with the encoder's 4^3 layers)");
     static_assert(GOUT == 0 && !CSUM, "the fused statistics of this kernel predate the 16-block contract (no instantiation uses them)");
-    constexpr int WTAP = NK * 64;            // float4 per tap
-    constexpr int PIECES = WTAP / (NW * 64); // 1 KiB pieces per wave per streamed tap
-    static_assert(!STREAM || (WTAP % (NW * 64) == 0 && KWG == 1), "streamed taps: one per step, split evenly over the waves");
+    // One step = KWG consecutive taps (input positions e.x .. e.x + KWG - 1, fragments e.y .. e.y + KWG - 1) = NGR groups of one
+    // channel octet x NMT cout tiles.  The next step's WSTEP float4 of weights travel global -> register -> LDS in 1 KiB pieces, one
+    // piece per wave every few groups (requested at the group's start, stored after its MFMAs: see REGW in conv_rows16_k for why not
+    // global_load_lds), into the other half of a double-buffered window; one barrier per step.
+    constexpr int WTAP = NK * 64, WSTEP = KWG * WTAP;   // float4 per tap / per step
+    constexpr int NGR = KWG * NU;                       // MFMA groups per step
+    constexpr int NPW = WSTEP / 64 / NW;                // weight pieces per wave and step
+    static_assert(WSTEP % (NW * 64) == 0, "streamed taps split evenly over the waves");
+    constexpr int PPG = (NPW + NGR - 1) / NGR;          // most pieces any group carries
+    auto piece_first = [](int g) { return (g * NPW + NGR - 1) / NGR; };   // piece k travels with group floor(k * NGR / NPW)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, q = lane >> 5;
     int tile = blockIdx.x * NW + wave;
     const bool active = tile < A.n_tiles;
-    if (!active) tile = A.n_tiles - 1;
-    const f32x4* wg4 = (const f32x4*)A.wfrag;
-    if (!STREAM) {
-        for (int i = threadIdx.x; i < A.n_taps * WTAP; i += NW * 64) lds[i] = wg4[i];
-        __syncthreads();
-        if (!active) return;
-    }
+    if (!active) tile = A.n_tiles - 1;   // a wave without a tile re-computes the last one (it carries its share of the weights)
 
     // ---- input transform, per lane: channels cin = 8u + 4q + i ----
     float ta[INMODE == 0 ? 1 : NU][4], tb[INMODE == 1 ? NU : 1][4];
@@ -590,42 +592,32 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
             for (int i = 0; i < 4; ++i) ta[u][i] = q ? gall[8 * u + 4 + i] : gall[8 * u + i];
     }
 
-    constexpr int NST = (GOUT > 0) ? NMT * 4 : 1;
-    GnAcc st[NST];
-#pragma unroll
-    for (int k = 0; k < NST; ++k) st[k].init();
-    float cs[CSUM ? NMT : 1][16];
-    if (CSUM) {
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cs[mt][r] = 0.0f;
-    }
-
-    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;
+    // activations and weights through buffer addressing (see buf_ld16): position ip, channel octet u of this lane; weight piece t of tap0
+    const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32);
+    const unsigned lane_b = (unsigned)(q * 32 + j) * 16u;
+    auto ldx = [&](int ip, int u) -> f32x4 { return buf_ld16(inb, lane_b + u * 1024, (unsigned)(ip < NPI ? ip : NPI - 1) * (CIN / 4) * 512u); };
+    const vq_buf wb = buf_of(A.wfrag);
+    auto ldw = [&](int tap0, int k) -> f32x4 { return buf_ld16(wb, (unsigned)lane * 16u, ((unsigned)tap0 * WTAP + (unsigned)(k * NW + wave) * 64u) * 16u); };
     const f32x4* bf4 = (const f32x4*)A.bias_frag;
     const int NS = A.n_steps;
+    // outputs: the leaf-tile activation (OUTMODE 0) or the tile's 32 leaves of the caller's leaf-major [n][512] buffer (OUTMODE 2)
+    const vq_buf outb = buf_of(OUTMODE == 2 ? (const void*)(A.out + (size_t)tile * 32 * 512) : (const void*)((const f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32));
+    const vq_buf skb = buf_of(RESID ? (const void*)((const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32) : (const void*)A.out);
 
-    // ---- pipeline prologue: table entries two ahead, operands one step ahead ----
+    // ---- prologue: the first step's weights into window si & 1, its positions into registers ----
     int g0, g1;
     split_range<NPO>(g0, g1);
     int si = gridDim.y > 1 ? A.grp_start[g0] : 0;
     int4 e = steps[si];
     int4 en = steps[si + 1 < NS ? si + 1 : NS - 1];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) lds[(si & 1) * WSTEP + (k * NW + wave) * 64 + lane] = ldw(e.y, k);
     f32x4 bn[KWG][NU];
 #pragma unroll
-    for (int k = 0; k < KWG; ++k) {
-        const int ipn = KWG == 1 ? e.x : min(e.x + k, NPI - 1);
+    for (int kg = 0; kg < KWG; ++kg)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) bn[k][u] = in4[(size_t)ipn * (CIN / 4) * 32 + u * 64];
-    }
-    if (STREAM) {
-#pragma unroll
-        for (int pc = 0; pc < PIECES; ++pc) {
-            const int piece = wave * PIECES + pc;
-            glds16(wg4 + (size_t)e.y * WTAP + piece * 64 + lane, lds + (si & 1) * WTAP + piece * 64);
-        }
-    }
+        for (int u = 0; u < NU; ++u) bn[kg][u] = ldx(e.x + kg, u);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // enter the loop with nothing in flight (see conv_rows16_k)
     for (int po = g0; po < g1; ++po) {
         f32x16 acc[NMT];
 #pragma unroll
@@ -634,60 +626,45 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
         bool last;
         do {
-            f32x4 bc[KWG][NU];
-#pragma unroll
-            for (int k = 0; k < KWG; ++k)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) bc[k][u] = bn[k][u];  // first use: waits for this step's prefetch
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];   // consumed one step later
-            if (STREAM) __syncthreads();  // every wave's pieces of W(s) landed; every wave done reading W(s-1)
-            // prefetch for the next step, unconditionally (the table index is clamped, so the final
-            // iteration re-requests valid data): keeps bn/LDS-window writes free of control flow
+            __syncthreads();   // every wave's pieces of W(s) are in LDS; every wave done reading W(s-1)
+            const f32x4* wl = lds + (si & 1) * WSTEP + lane;
+            f32x4 a_nx = wl[0];
 #pragma unroll
-            for (int k = 0; k < KWG; ++k) {
-                const int ipn = KWG == 1 ? en.x : min(en.x + k, NPI - 1);
+            for (int g = 0; g < NGR; ++g) {
+                const int kg = g / NU, u = g % NU;
+                f32x4 wnext[PPG];
 #pragma unroll
-                for (int u = 0; u < NU; ++u) bn[k][u] = in4[(size_t)ipn * (CIN / 4) * 32 + u * 64];
-            }
-            if (STREAM) {
-                f32x4* dst = lds + ((si + 1) & 1) * WTAP;
-#pragma unroll
-                for (int pc = 0; pc < PIECES; ++pc) {
-                    const int piece = wave * PIECES + pc;
-                    glds16(wg4 + (size_t)en.y * WTAP + piece * 64 + lane, dst + piece * 64);
+                for (int jp = 0; jp < PPG; ++jp)
+                    if (piece_first(g) + jp < piece_first(g + 1)) wnext[jp] = ldw(en.y, piece_first(g) + jp);
+                __builtin_amdgcn_sched_barrier(0);   // requested here, a whole group ahead of the ds_write
+                f32x4 b = bn[kg][u];
+                if (INMODE == 1) {
+                    b.x = fmaxf(__builtin_fmaf(b.x, ta[u][0], tb[u][0]), 0.0f);
+                    b.y = fmaxf(__builtin_fmaf(b.y, ta[u][1], tb[u][1]), 0.0f);
+                    b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
+                    b.w = fmaxf(__builtin_fmaf(b.w, ta[u][3], tb[u][3]), 0.0f);
+                } else if (INMODE == 2) {
+                    b.x = b.x * ta[u][0];
+                    b.y = b.y * ta[u][1];
+                    b.z = b.z * ta[u][2];
+                    b.w = b.w * ta[u][3];
                 }
-            }
 #pragma unroll
-            for (int kg = 0; kg < KWG; ++kg) {
-                if (kg < (e.w >> 8)) {
-                    const f32x4* wl = (STREAM ? lds + (si & 1) * WTAP : lds + (size_t)(e.y + kg) * WTAP) + lane;
-                    f32x4 a_nx = wl[0];
-                    f32x4 b;
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        const int u = k / NMT, mt = k % NMT;
-                        const f32x4 a = a_nx;
-                        if (k + 1 < NK) a_nx = wl[(k + 1) * 64];  // LDS A-fragment one group ahead of its MFMAs
-                        if (mt == 0) {
-                            b = bc[kg][u];
-                            if (INMODE == 1) {
-                                b.x = fmaxf(__builtin_fmaf(b.x, ta[u][0], tb[u][0]), 0.0f);
-                                b.y = fmaxf(__builtin_fmaf(b.y, ta[u][1], tb[u][1]), 0.0f);
-                                b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
-                                b.w = fmaxf(__builtin_fmaf(b.w, ta[u][3], tb[u][3]), 0.0f);
-                            } else if (INMODE == 2) {
-                                b.x = b.x * ta[u][0];
-                                b.y = b.y * ta[u][1];
-                                b.z = b.z * ta[u][2];
-                                b.w = b.w * ta[u][3];
-                            }
-                        }
-                        acc[mt] = mfma32(a.x, b.x, acc[mt]);
-                        acc[mt] = mfma32(a.y, b.y, acc[mt]);
-                        acc[mt] = mfma32(a.z, b.z, acc[mt]);
-                        acc[mt] = mfma32(a.w, b.w, acc[mt]);
-                    }
+                for (int mt = 0; mt < NMT; ++mt) {
+                    const f32x4 a = a_nx;
+                    if (g * NMT + mt + 1 < NGR * NMT) a_nx = wl[(g * NMT + mt + 1) * 64];   // LDS A fragment one group ahead of its MFMAs
+                    acc[mt] = mfma32(a.x, b.x, acc[mt]);
+                    acc[mt] = mfma32(a.y, b.y, acc[mt]);
+                    acc[mt] = mfma32(a.z, b.z, acc[mt]);
+                    acc[mt] = mfma32(a.w, b.w, acc[mt]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                bn[kg][u] = ldx(en.x + kg, u);   // the next step's position, right after this one's last use (index clamped)
+#pragma unroll
+                for (int jp = 0; jp < PPG; ++jp)
+                    if (piece_first(g) + jp < piece_first(g + 1))
+                        lds[((si + 1) & 1) * WSTEP + ((piece_first(g) + jp) * NW + wave) * 64 + lane] = wnext[jp];
             }
             last = (e.w & 2) != 0;
             e = en;
@@ -701,8 +678,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    skv[mt][g] = ((const f32x4*)A.skip)[(((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j];
+                for (int g = 0; g < 4; ++g) skv[mt][g] = buf_ld16(skb, lane_b + (8 * mt + 2 * g) * 512, (unsigned)po * (COUT / 4) * 512u);
         }
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
@@ -720,62 +696,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     const f32x4 u = v * 0.1f;
                     v = skv[mt][g] + u;
                 }
-                if (OUTMODE == 0 && active) ((f32x4*)A.out)[o] = v;
+                if (OUTMODE == 0 && active) buf_st16(v, outb, lane_b + (8 * mt + 2 * g) * 512, (unsigned)po * (COUT / 4) * 512u);
                 if (OUTMODE == 2) {
                     // rows 32mt + 8g + 4q + {0..3} of slab po are 4 consecutive voxels of this lane's leaf
                     const int64_t leaf = (int64_t)tile * 32 + j;
                     if (active && leaf < A.n_leaves) {
                         f32x4 sg;
                         sg.x = vq_sigmoid(v.x), sg.y = vq_sigmoid(v.y), sg.z = vq_sigmoid(v.z), sg.w = vq_sigmoid(v.w);
-                        *(f32x4*)(A.out + leaf * 512 + po * 128 + 32 * mt + 8 * g + 4 * q) = sg;
+                        buf_st16(sg, outb, (unsigned)(j * 512 + 4 * q) * 4u, (unsigned)(po * 128 + 32 * mt + 8 * g) * 4u);
                     }
-                }
-                if (GOUT > 0) {
-                    st[mt * 4 + g].add(v.x);
-                    st[mt * 4 + g].add(v.y);
-                    st[mt * 4 + g].add(v.z);
-                    st[mt * 4 + g].add(v.w);
-                }
-                if (CSUM) {
-                    cs[mt][4 * g + 0] = cs[mt][4 * g + 0] + v.x;
-                    cs[mt][4 * g + 1] = cs[mt][4 * g + 1] + v.y;
-                    cs[mt][4 * g + 2] = cs[mt][4 * g + 2] + v.z;
-                    cs[mt][4 * g + 3] = cs[mt][4 * g + 3] + v.w;
                 }
             }
         }
-    }
-    if (!active) return;
-    if (GOUT > 0) {
-        constexpr int CPGO = COUT / (GOUT > 0 ? GOUT : 1);
-        static_assert(GOUT == 0 || CPGO == 4 || CPGO == 8, "stats groups of 4 or 8 channels");
-        const double inv_n = 1.0 / (double)(CPGO * NPO);
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                double S = st[mt * 4 + g].s, Q = st[mt * 4 + g].q;
-                if (CPGO == 8) {
-                    S = S + shfl_xor32_f64(S);
-                    Q = Q + shfl_xor32_f64(Q);
-                }
-                float m, r;
-                gn_finish(S, Q, inv_n, m, r);
-                const int grp = CPGO == 4 ? 8 * mt + 2 * g + q : 4 * mt + g;
-                if (CPGO == 4 || q == 0) {
-                    A.out_mean[((size_t)tile * GOUT + grp) * 32 + j] = m;
-                    A.out_rstd[((size_t)tile * GOUT + grp) * 32 + j] = r;
-                }
-            }
-    }
-    if (CSUM) {
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q;
-                A.out_csum[((size_t)tile * COUT + co) * 32 + j] = cs[mt][r];
-            }
     }
 }
 
