@@ -86,6 +86,7 @@ struct vqhip_codec {
     int64_t chunk = 65536;
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: stem_fused_k; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
+    bool conv8_w16 = true;   // ... its residual conv (no statistics) with 16 waves (half rows); VQHIP_CONV8=w8 selects 8
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
@@ -807,6 +808,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_dec_r64c1_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<false, true, 8, 0, true>, LDS_CONV8))) return rc;
+    if ((rc = set_lds(c, conv8_lds_k<true, false, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
@@ -1005,7 +1007,8 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rowgroups8_4"];
-        if (c->conv8_lds) L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_lds_k<true, false, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
+        if (c->conv8_lds && c->conv8_w16) L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_lds_k<true, false, 16, 0, false>), dim3(std::min(2 * nt, c->n_cus)), dim3(1024), LDS_CONV8, s, A); });
+        else if (c->conv8_lds) L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_lds_k<true, false, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
         else L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
     }
     {
@@ -1464,7 +1467,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
         return bail(VQHIP_ERR_DEVICE);
     }
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0;
+    if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
