@@ -156,9 +156,14 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
     // K slot q4 = kw (3 = pad).  A lane's eight B operands of a row, x[ow + kw - 1] for ow = 0..7, are the 8 floats starting at
     // element kw of the row's record (0, x0..x7, 0): two 16-byte loads at 4-byte alignment.  The pad slot reads a record of zeros
     // (stride 0), so it contributes fmaf(0, 0, acc) exactly like the contract says.
-    const float* x = q4 < 3 ? A.in + (size_t)tile * VQ_XR_TILE + jj * VQ_XR_REC + q4 : A.zeros;
-    const int rstride = q4 < 3 ? 32 * VQ_XR_REC : 0, sbstride = q4 < 3 ? 16 * VQ_XR_REC : 0;
-    f32x4* out4 = A.out ? (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
+    // Buffer addressing (see buf_ld16): row r, sub-tile sb, half row hf of this lane's K slot.  The pad slot's lane offset lies beyond
+    // the descriptor's range, and an out-of-range buffer load returns 0.
+    const vq_buf xb = buf_of(A.in + (size_t)tile * VQ_XR_TILE);
+    const unsigned lane_x = q4 < 3 ? (unsigned)(jj * VQ_XR_REC + q4) * 4u : 0x80000000u;
+    auto ldrow = [&](int r, int sb, int hf) -> f32x4 { return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u); };
+    const bool has_out = A.out != nullptr;
+    const vq_buf outb = buf_of(has_out ? (const f32x4*)A.out + (size_t)tile * 512 * 4 * 32 : (const f32x4*)A.in);
+    const unsigned lane_o = (unsigned)(q4 * 32 + jj) * 16u;
     float ia[2][4], ib[2][4];  // MODE 1: GroupNorm(4,16) of y1, group = q4 (this lane's 4 couts)
     if (MODE == 1) {
 #pragma unroll
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
         const int r = max(0, min((e.x >> 3) + (kh - 1), 63));
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
-            xn[kh][sb][0] = *(const f32x4u*)(x + r * rstride + sb * sbstride);
-            xn[kh][sb][1] = *(const f32x4u*)(x + r * rstride + sb * sbstride + 4);
+            xn[kh][sb][0] = ldrow(r, sb, 0);
+            xn[kh][sb][1] = ldrow(r, sb, 1);
         }
     }
     for (int row = g0; row < g1; ++row) {
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                 const int r = max(0, min((en.x >> 3) + (kh - 1), 63));
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
-                    xn[kh][sb][0] = *(const f32x4u*)(x + r * rstride + sb * sbstride);
-                    xn[kh][sb][1] = *(const f32x4u*)(x + r * rstride + sb * sbstride + 4);
+                    xn[kh][sb][0] = ldrow(r, sb, 0);
+                    xn[kh][sb][1] = ldrow(r, sb, 1);
                 }
             }
             // e.y = kd selects the weight registers; a 3-way uniform select keeps the register index static
@@ -242,13 +247,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
             for (int sb = 0; sb < 2; ++sb) {
                 f32x4 v = acc[ow][sb] + bias4;
                 if (MODE == 2) {  // plain conv output + statistics partials (position-split path)
-                    out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;
+                    buf_st16(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);
                     st[sb][0].add(v.x);
                     st[sb][0].add(v.y);
                     st[sb][0].add(v.z);
                     st[sb][0].add(v.w);
                 } else if (MODE == 0) {
-                    if (out4) out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb] = v;   // debug only
+                    if (has_out) buf_st16(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);   // debug only
                     st[sb][0].add(v.x);
                     st[sb][0].add(v.y);
                     st[sb][0].add(v.z);
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     v.w = fmaxf(__builtin_fmaf(v.w, ia[sb][3], ib[sb][3]), 0.0f);
                     // streaming (nontemporal) store: the 2.1 GB of a1 are read by the next kernel from HBM anyway, and a plain store's
                     // write-allocate traffic through L2 made this pass store-bound (0.65 -> 0.45 ms)
-                    __builtin_nontemporal_store(v, &out4[((size_t)(row * 8 + ow) * 4) * 32 + 16 * sb]);
+                    buf_st16_nt(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);
                     st[sb][0].add(v.x);
                     st[sb][0].add(v.y);
                     st[sb][1].add(v.z);
