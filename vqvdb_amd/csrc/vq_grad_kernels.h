@@ -373,25 +373,51 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     constexpr int PD = 1;   // prefetch distance in steps (3 measured no better: r64 layers -2 %, stem and r32 layers +10 %)
     const int npairs = s1 - s0, nsteps = (t1 - t0) * npairs;
     f32x4 rdy[PD][ND], rx[PD][NX];
+    // (buffer addressing, see buf_ld16: the block of a position is one contiguous run, thread i takes float4 i)
     auto fetch = [&](int k, f32x4 (&qdy)[ND], f32x4 (&qx)[NX]) {
         if (k >= nsteps) return;   // (uniform)
         const int tile = t0 + k / npairs;
         const int2 e = A.wsteps[s0 + k % npairs];   // x = input position, y = output position
+        const vq_buf dyb = buf_of((const f32x4*)A.dy + (size_t)tile * NPO * (COUT / 4) * 32);
+        const vq_buf xb = buf_of((const f32x4*)A.x + (size_t)tile * NPI * (CIN / 4) * 32);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int i = threadIdx.x + d * NT;
-            if (i < (COUT / 4) * 32) qdy[d] = ((const f32x4*)A.dy)[(((size_t)tile * NPO + e.y) * (COUT / 4) + (i >> 5)) * 32 + (i & 31)];
+            if (i < (COUT / 4) * 32) qdy[d] = buf_ld16(dyb, (unsigned)i * 16u, (unsigned)e.y * (COUT / 4) * 512u);
         }
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             const int i = threadIdx.x + d * NT;
-            if (i < (CIN / 4) * 32) qx[d] = ((const f32x4*)A.x)[(((size_t)tile * NPI + e.x) * (CIN / 4) + (i >> 5)) * 32 + (i & 31)];
+            if (i < (CIN / 4) * 32) qx[d] = buf_ld16(xb, (unsigned)i * 16u, (unsigned)e.x * (CIN / 4) * 512u);
+        }
+    };
+    // the input transform of this thread's channels (GroupNorm scale / shift or attention gate): per (tile, channel, leaf), so it
+    // changes only when the tile does — it used to be re-loaded in every step, 8-16 scalar loads per 16 MFMAs
+    float tia[NX][4], tib[NX][4];
+    auto load_transform = [&](int tile) {
+#pragma unroll
+        for (int dd = 0; dd < NX; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (CIN / 4) * 32) {
+                const int quad = i >> 5, leaf = i & 31;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = 4 * quad + kk;
+                    if (INMODE == 1) {
+                        const int g = ch / CPG;
+                        tia[dd][kk] = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
+                        tib[dd][kk] = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], tia[dd][kk], A.beta[ch]);
+                    } else if (INMODE == 2) {
+                        tia[dd][kk] = A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
+                    }
+                }
+            }
         }
     };
     // one step: blocks of step k (in registers) -> LDS ([leaf][channel], GroupNorm+ReLU / gate applied to X on the way), request step
     // k + PD into the registers just freed, MFMAs
     auto step = [&](int k, f32x4 (&qdy)[ND], f32x4 (&qx)[NX]) {
-        const int tile = t0 + k / npairs;
+        if (INMODE != 0 && k % npairs == 0) load_transform(t0 + k / npairs);   // (uniform)
         __syncthreads();              // previous step's MFMAs have read the blocks
 #pragma unroll
         for (int dd = 0; dd < ND; ++dd) {
@@ -407,15 +433,8 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
                 float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int ch = 4 * quad + kk;
-                    if (INMODE == 1) {
-                        const int g = ch / CPG;
-                        const float ia = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
-                        const float ibb = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], ia, A.beta[ch]);
-                        o[kk] = fmaxf(__builtin_fmaf(o[kk], ia, ibb), 0.0f);
-                    } else if (INMODE == 2) {
-                        o[kk] = o[kk] * A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
-                    }
+                    if (INMODE == 1) o[kk] = fmaxf(__builtin_fmaf(o[kk], tia[dd][kk], tib[dd][kk]), 0.0f);
+                    else if (INMODE == 2) o[kk] = o[kk] * tia[dd][kk];
                 }
                 *(f32x4*)&sx[leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
             }
