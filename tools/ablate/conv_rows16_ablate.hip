@@ -74,7 +74,15 @@ int main()
         hipEventRecord(a, 0); for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 15) / 16), dim3(1024), LDS32, 0, B, steps); \
         hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); \
         printf("enc res32 conv1, ABL %-3d                                  %8.4f ms  (%s)\n", ABL, ms / 5, hipGetErrorString(hipGetLastError())); }
-        R32(0) R32(4) R32(8) R32(16) R32(32) R32(60)
+        R32(0) R32(8) R32(32) R32(60)
+#define R32K(ABL) { auto k = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 16, false, ABL, true>; \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32); \
+        hipEvent_t a, b; hipEventCreate(&a), hipEventCreate(&b); \
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 15) / 16), dim3(1024), LDS32, 0, B, steps); \
+        hipEventRecord(a, 0); for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 15) / 16), dim3(1024), LDS32, 0, B, steps); \
+        hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); \
+        printf("enc res32 conv1, kw-outer, ABL %-3d                        %8.4f ms  (%s)\n", ABL, ms / 5, hipGetErrorString(hipGetLastError())); }
+        R32K(0) R32K(128)
     }
     {   // encoder down conv: 16 -> 32 k4 s2 @8^3 -> 4^3, weights LDS-resident (128 KB), 8 waves, two-step prefetch
         std::vector<int> t3 = steps_rows(8, 4, 4, 2, 1);
@@ -91,7 +99,15 @@ int main()
         hipEventRecord(a, 0); for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDSD, 0, B, steps3); \
         hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); \
         printf("enc down, ABL %-3d                                         %8.4f ms  (%s)\n", ABL, ms / 5, hipGetErrorString(hipGetLastError())); }
-        RD(0) RD(4) RD(8) RD(32) RD(44)
+        RD(0) RD(8) RD(32) RD(44)
+#define RDK(ABL) { auto k = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, false, ABL, true>; \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSD); \
+        hipEvent_t a, b; hipEventCreate(&a), hipEventCreate(&b); \
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDSD, 0, B, steps3); \
+        hipEventRecord(a, 0); for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3((2 * nt + 7) / 8), dim3(512), LDSD, 0, B, steps3); \
+        hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); \
+        printf("enc down, kw-outer (no PF2), ABL %-3d                      %8.4f ms  (%s)\n", ABL, ms / 5, hipGetErrorString(hipGetLastError())); }
+        RDK(0) RDK(128)
     }
     return 0;
 }

@@ -828,7 +828,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     // trip per step with the matrix pipe idle, for both waves of a SIMD at once.  With plain loads every wait is an exact count.
     constexpr int NPCW = (WSTEPL / 64) / NWV;                    // weight pieces (1 KiB) per wave and step
     constexpr bool REGW = KWO && !RESIDENT && (WSTEPL / 64) % NWV == 0 && !(ABL & 2);
-    constexpr bool APF = REGW && !(ABL & 128);                   // A fragments read one group ahead (ABL 128: at the group's start)
+    constexpr bool APF = KWO && (REGW || RESIDENT) && !(ABL & 128);   // A fragments read one group ahead (ABL 128: at the group's start)
     constexpr int CPW = APF ? 1 : (CBN % 2 == 0 ? 2 : 1);        // channel blocks per kw-outer MFMA group
     constexpr int NGRP = KS * (CBN / CPW);                       // MFMA groups per step
     constexpr int PPG = REGW ? (NPCW + NGRP - 1) / NGRP : 1;     // most pieces any group carries
