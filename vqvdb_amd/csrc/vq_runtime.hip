@@ -1043,7 +1043,10 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         VqArgs A{};
         A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
         A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
-        L.run("enc_vq", [&] { hipLaunchKernelGGL(vq_folded_k<8>, dim3(g8), dim3(512), 0, s, A); });
+        // two position ranges per tile: 2 x n_tiles waves = 4 per SIMD on a full chunk (one wave per tile leaves 2, and the wave's
+        // MFMA chain -> argmin scan -> next chain sequence has nobody to overlap with)
+        static const int vq_split = std::getenv("VQHIP_VQ_SPLIT") ? std::atoi(std::getenv("VQHIP_VQ_SPLIT")) : 2;
+        L.run("enc_vq", [&] { hipLaunchKernelGGL(vq_folded_k<8>, dim3(g8, vq_split), dim3(512), 0, s, A); });
     }
     return L.rc;
 }
