@@ -1356,8 +1356,11 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float c = i == 0 ? ck[g].x : (i == 1 ? ck[g].y : (i == 2 ? ck[g].z : ck[g].w));
-                    const float score = c - 2.0f * d[4 * g + i];
-                    const int k = 32 * ct + i + 8 * g + 4 * q;
+                    // c - 2*dot in one rounding either way (2*dot is exact): one fused op instead of an add and a subtract; the lane's
+                    // own code offset 4q is added after the scan so that the candidate index is wave-uniform (an immediate operand
+                    // of the select, not a per-candidate vector add) — 4 vector ops per candidate instead of 6
+                    const float score = __builtin_fmaf(-2.0f, d[4 * g + i], c);
+                    const int k = 32 * ct + i + 8 * g;
                     if (score < best) {
                         best = score;
                         bk = k;
@@ -1365,6 +1368,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
                 }
             }
         }
+        bk += 4 * q;
         const float ob = __shfl_xor(best, 32, 64);
         const int ok = __shfl_xor(bk, 32, 64);
         if (ob < best || (ob == best && ok < bk)) bk = ok;
