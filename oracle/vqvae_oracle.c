@@ -34,7 +34,7 @@
  *   * GroupNorm statistics: fp64 accumulators under the 16-BLOCK RULE (gn_stats below): the positions of a leaf form 16 equal
  *     blocks (32 positions at 8^3, one row of 4 at 4^3); inside a block ONE sequential chain starting from zero, positions
  *     ascending and, inside a position, the accumulator's channels ascending; the 16 block sums are then added in block order.
- *     One tensor uses 64 blocks (one W-row of 8 positions each, added row-major: see gn_stats_nb) instead: the output of the
+ *     One tensor uses 128 blocks (HALF a W-row = 4 positions each, added row-major: see gn_stats_nb) instead: the output of the
  *     16-channel residual block's first conv at 8^3 (statistics for its gn2).
  *     Groups of 8 channels are the sum of two such accumulators (low 4, high 4 channels), low + high.
  *     mean = S/N, var = fma(-mean,mean,Q/N) clamped at 0, rstd = 1/sqrt(var+1e-5) in fp64,
@@ -389,19 +389,19 @@ static void gn_stats_nb(const float* x, int C, int G, int NP, int NBLK, float* m
                ascending, channels ascending) starting from zero.
                NBLK = 16 (everywhere but one tensor): the block sums are added in block order — a launch that splits a layer over
                up to 16 position ranges can fuse the statistics as per-block partials.
-               NBLK = 64 (output of the 16-channel residual block's first conv at 8^3): a block is one W-row of 8 positions,
-               block (od, oh) = od*8 + oh, and the blocks are added ROW-MAJOR: for oh = 0..7 { t = sum over od = 0..7 of
-               block(od, oh), from zero, od ascending }, the eight t added in oh order.  That is the order of the LDS-plane
-               kernel conv8_lds_k, where a wave owns row oh of every plane of its half tile. */
+               NBLK = 128 (output of the 16-channel residual block's first conv at 8^3): a block is HALF a W-row (4 positions),
+               block (od, oh, hw) = od*16 + oh*2 + hw = position / 4, and the blocks are added ROW-MAJOR: for o = (oh, hw) = 0..15
+               { t = sum over od = 0..7 of block(od, o), from zero, od ascending }, the sixteen t added in o order.  That is the
+               order of the LDS-plane kernel conv8_lds_k, where a wave owns half row (oh, hw) of every plane of its half tile. */
             double s[LT], q[LT];
             for (int l = 0; l < LT; ++l) s[l] = q[l] = 0.0;
             const int BP = NP / NBLK;
-            const int outer = NBLK == 64 ? 8 : 1, inner = NBLK / outer;
+            const int outer = NBLK == 128 ? 16 : 1, inner = NBLK / outer;
             for (int o = 0; o < outer; ++o) {
                 double ts[LT], tq[LT];
                 for (int l = 0; l < LT; ++l) ts[l] = tq[l] = 0.0;
                 for (int i = 0; i < inner; ++i) {
-                    const int b = NBLK == 64 ? i * 8 + o : i;     /* 64: od = i, oh = o */
+                    const int b = NBLK == 128 ? i * 16 + o : i;   /* 128: od = i, (oh, hw) = o */
                     double sb[LT], qb[LT];
                     for (int l = 0; l < LT; ++l) sb[l] = qb[l] = 0.0;
                     for (int p = b * BP; p < (b + 1) * BP; ++p)
@@ -465,7 +465,7 @@ static void res_block(const float* x, float* out, float* t0, float* t1, int C, i
     gn_relu(x, t0, C, 8, NP, mean, rstd, W[base + 0], W[base + 1]);
     conv3d(t0, t1, W[base + 2], W[base + 3], C, C, S, S, 3, 1, 1, kord);
     if (y_mid_dump) memcpy(y_mid_dump, t1, sizeof(float) * C * NP * LT);
-    gn_stats_nb(t1, C, 8, NP, (C == 16 && S == 8) ? 64 : 16, mean, rstd);   /* row blocks for the 8^3 block's conv1 output */
+    gn_stats_nb(t1, C, 8, NP, (C == 16 && S == 8) ? 128 : 16, mean, rstd);   /* half-row blocks for the 8^3 block's conv1 output */
     gn_relu(t1, t0, C, 8, NP, mean, rstd, W[base + 4], W[base + 5]);
     /* conv2 without bias add, then out = x + 0.1*(acc + bias) */
     static const float zero_bias[256] = {0};

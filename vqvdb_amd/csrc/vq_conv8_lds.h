@@ -16,9 +16,9 @@
 // for bit.  The workgroup is persistent: it walks half tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the plane pipeline runs
 // straight across the boundary (the next half tile's plane 0 is prefetched during the last plane of the current one).
 //
-// Statistics (STATS, conv1): each output ROW is one statistics block of this tensor (64 row blocks added row-major): a
-// wave adds the 8 positions of its row in one fp64 chain from zero, adds these row blocks over the 8 planes in its registers, and
-// stores the eight per-wave totals; gn_combine_k<false> adds them in oh order.
+// Statistics (STATS, conv1): each output HALF ROW is one statistics block of this tensor (128 half-row blocks added row-major, DESIGN
+// 4): a wave adds the 4 positions of a half row in one fp64 chain from zero, adds these blocks over the 8 planes in its registers,
+// and stores the per-half-row totals (16 per half tile); gn_combine_k<false> adds them in (oh, hw) order.
 #pragma once
 #include "vq_kernels.h"
 
@@ -38,7 +38,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
 {
     static_assert(!LD2 || NW == 8, "border-row loaders: the 8-wave variant");
     static_assert(NW == 8 || NW == 16, "8 waves: one output row each; 16 waves: one half row (4 positions) each");
-    static_assert(!(STATS && NW == 16), "row statistics need whole rows");
     constexpr int NT = NW * 64, OWN = 64 / NW;   // threads; output positions (and loader positions) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* wl = (f32x4*)smem_raw;          // [27 taps][64 lanes]
@@ -101,8 +100,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
     };
 
     f32x4 acc[OWN];
-    GnAcc st[2];   // STATS: running sums of this wave's row over the planes of the current half tile
-    st[0].init(), st[1].init();
+    // STATS: running sums of this wave's half row(s) over the planes of the current half tile ([half row of the wave][group of the quad])
+    constexpr int HW = NW == 8 ? 2 : 1;
+    GnAcc st[HW][2];
+#pragma unroll
+    for (int h = 0; h < HW; ++h) st[h][0].init(), st[h][1].init();
     // the taps of one kd: input plane in `slot`, rows oh-1 .. oh+1
     // valid kh of this wave's row (zero padding: the other taps do not exist): k0 .. k0 + nk - 1
     const int k0 = oh == 0 ? 1 : 0, nk = (oh == 0 || oh == 7) ? 2 : 3;
@@ -190,24 +192,28 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
             if (!(ABL & 2)) buf_st16_nt(v, outb, lane_b, (unsigned)((od * 8 + oh) * 8 + ow0 + ow) * 2048u);
             if ((ABL & 2) && ow == 0 && v.x == 12345.678f) out4[0] = v;   // keep the accumulators alive
             if (STATS && !(ABL & 2)) {
-                st[0].add(v.x);
-                st[0].add(v.y);
-                st[1].add(v.z);
-                st[1].add(v.w);
+                constexpr int HP = OWN / HW;   // positions per half row of this wave (4)
+                st[ow / HP][0].add(v.x);
+                st[ow / HP][0].add(v.y);
+                st[ow / HP][1].add(v.z);
+                st[ow / HP][1].add(v.w);
             }
         }
         if (STATS && !(ABL & 2)) {
-            // the row is one statistics block; this wave owns row oh of every plane, and the contract adds the 64 row blocks
-            // row-major: t_oh = sum over od (from zero, od ascending) lives in this wave's registers, the eight t_oh go to blocks
-            // 0..7 of the 16-block partial buffer (blocks 8..15 = 0) and gn_combine_k<false> adds them in oh order
-            st[0].fold(), st[1].fold();
+            // HALF a row (4 positions) is one statistics block; a wave owns half row (oh, hw) of every plane (both halves with 8 waves),
+            // and the contract adds the 128 half-row blocks row-major: t_(oh,hw) = sum over od (from zero, od ascending) lives in this
+            // wave's registers, the sixteen t go to the 16 blocks of the partial buffer and gn_combine_k<false> adds them in order
+#pragma unroll
+            for (int h = 0; h < HW; ++h) st[h][0].fold(), st[h][1].fold();
             if (od == 7) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    A.part_s[part_index(tile, oh, 2 * q4 + k, jj)] = st[k].s, A.part_q[part_index(tile, oh, 2 * q4 + k, jj)] = st[k].q;
-                    A.part_s[part_index(tile, oh + 8, 2 * q4 + k, jj)] = 0.0, A.part_q[part_index(tile, oh + 8, 2 * q4 + k, jj)] = 0.0;
-                    st[k].init();
-                }
+                for (int h = 0; h < HW; ++h)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int blk = NW == 8 ? 2 * oh + h : wave;
+                        A.part_s[part_index(tile, blk, 2 * q4 + k, jj)] = st[h][k].s, A.part_q[part_index(tile, blk, 2 * q4 + k, jj)] = st[h][k].q;
+                        st[h][k].init();
+                    }
             }
         }
     }

@@ -118,8 +118,9 @@ struct GnAcc {
 };
 // index of (tile, statistics block, accumulator slot, leaf) in the partial buffers: 16 blocks x 16 slots x 32 leaves per tile
 __device__ __forceinline__ size_t part_index(int tile, int blk, int slot, int leaf) { return (((size_t)tile * 16 + blk) * 16 + slot) * 32 + leaf; }
-// ... and for the one tensor with 64 row blocks (conv1 output of the 16-channel residual block): 64 rows x 8 slots x 32 leaves per tile
-__device__ __forceinline__ size_t part_index_rows(int tile, int row, int slot, int leaf) { return (((size_t)tile * 64 + row) * 8 + slot) * 32 + leaf; }
+// ... and for the one tensor with 128 half-row blocks (conv1 output of the 16-channel residual block): half row hrow = position / 4
+// = (od*8 + oh)*2 + hw; 128 half rows x 8 slots x 32 leaves per tile
+__device__ __forceinline__ size_t part_index_rows(int tile, int hrow, int slot, int leaf) { return (((size_t)tile * 128 + hrow) * 8 + slot) * 32 + leaf; }
 // mean / rstd from total sums over n = 2^k elements (fp64, rounded to fp32 at the end)
 __device__ __forceinline__ void gn_finish(double S, double Q, double inv_n, float& mean, float& rstd)
 {

@@ -516,15 +516,16 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                     st[0].add(v.y);
                     st[1].add(v.z);
                     st[1].add(v.w);
+                    if ((ow & 3) == 3) {   // half an output row closed = one statistics block of this tensor (128 half-row blocks per leaf)
+                        const int hrow = 2 * ((obase >> 3) + rw) + (ow >> 2);
+                        st[0].fold_store(A.part_s, A.part_q, part_index_rows(tile, hrow, 2 * q4 + 0, jj));   // slot = GroupNorm(8,16) group
+                        st[1].fold_store(A.part_s, A.part_q, part_index_rows(tile, hrow, 2 * q4 + 1, jj));
+                    }
                 }
-            }
-            if (STATS) {   // one output row closed = one statistics block of this tensor (64 row blocks per leaf)
-                st[0].fold_store(A.part_s, A.part_q, part_index_rows(tile, (obase >> 3) + rw, 2 * q4 + 0, jj));   // slot = GroupNorm(8,16) group
-                st[1].fold_store(A.part_s, A.part_q, part_index_rows(tile, (obase >> 3) + rw, 2 * q4 + 1, jj));
             }
         }
     }
-    // (the row blocks of this tensor are added row-major, not in the order a wave produces them: gn_combine_k<false, true> finishes;
+    // (the half-row blocks of this tensor are added row-major, not in the order a wave produces them: gn_combine_k<false, true> finishes;
     // every STATS launch passes the partial buffers)
 }
 
@@ -1710,8 +1711,8 @@ __global__ __launch_bounds__(64 * C / 8) void gn_stats_seq_k(const float* __rest
     }
 }
 
-// ... and for the tensor whose statistics blocks are its 64 output rows, added row-major (conv1 output of the 16-channel residual
-// block): wave = channel quads (2w, 2w+1), GroupNorm(8,16): 2 channels per group.
+// ... and for the tensor whose statistics blocks are its 128 output HALF rows, added row-major (conv1 output of the 16-channel
+// residual block): wave = channel quads (2w, 2w+1), GroupNorm(8,16): 2 channels per group.
 __global__ __launch_bounds__(128) void gn_stats_rows16_k(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd)
 {
     const int lane = threadIdx.x & 63, j = lane & 31;
@@ -1719,16 +1720,16 @@ __global__ __launch_bounds__(128) void gn_stats_rows16_k(const float* __restrict
     const int tile = blockIdx.x;
     const f32x4* in4 = (const f32x4*)x + (size_t)tile * 512 * 4 * 32 + quad * 32 + j;
     double S[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
-    for (int oh = 0; oh < 8; ++oh) {
+    for (int o = 0; o < 16; ++o) {   // half row (oh, hw) = o
         double ts[2] = {0.0, 0.0}, tq[2] = {0.0, 0.0};
         for (int od = 0; od < 8; ++od) {
-            f32x4 v[8];
+            f32x4 v[4];
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) v[ow] = in4[(size_t)((od * 8 + oh) * 8 + ow) * 4 * 32];
+            for (int ow = 0; ow < 4; ++ow) v[ow] = in4[(size_t)((od * 16 + o) * 4 + ow) * 4 * 32];
             GnAcc a[2];
             a[0].init(), a[1].init();
 #pragma unroll
-            for (int ow = 0; ow < 8; ++ow) a[0].add(v[ow].x), a[0].add(v[ow].y), a[1].add(v[ow].z), a[1].add(v[ow].w);
+            for (int ow = 0; ow < 4; ++ow) a[0].add(v[ow].x), a[0].add(v[ow].y), a[1].add(v[ow].z), a[1].add(v[ow].w);
             ts[0] += a[0].bs, tq[0] += a[0].bq, ts[1] += a[1].bs, tq[1] += a[1].bq;
         }
         S[0] += ts[0], Q[0] += tq[0], S[1] += ts[1], Q[1] += tq[1];
@@ -1798,13 +1799,13 @@ __global__ __launch_bounds__(512) void gn_combine_k(const double* __restrict__ p
 {
     const int tile = blockIdx.x, slot = threadIdx.x >> 5, j = threadIdx.x & 31;
     double S = 0.0, Q = 0.0;
-    if (ROWS) {   // the tensor with 64 row blocks (8 slots), added row-major: conv1 output of the 16-channel residual block
-        for (int oh = 0; oh < 8; ++oh) {
+    if (ROWS) {   // the tensor with 128 half-row blocks (8 slots), added row-major: conv1 output of the 16-channel residual block
+        for (int o = 0; o < 16; ++o) {   // half row (oh, hw) = o
             double ts = 0.0, tq = 0.0;
 #pragma unroll
             for (int od = 0; od < 8; ++od) {
-                ts += ps[part_index_rows(tile, od * 8 + oh, slot, j)];
-                tq += pq[part_index_rows(tile, od * 8 + oh, slot, j)];
+                ts += ps[part_index_rows(tile, od * 16 + o, slot, j)];
+                tq += pq[part_index_rows(tile, od * 16 + o, slot, j)];
             }
             S += ts;
             Q += tq;

@@ -86,7 +86,7 @@ struct vqhip_codec {
     int64_t chunk = 65536;
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: stem_fused_k; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
-    bool conv8_w16 = true;   // ... its residual conv (no statistics) with 16 waves (half rows); VQHIP_CONV8=w8 selects 8
+    bool conv8_w16 = true;   // ... with 16 waves (one half row each; a half row is a statistics block); VQHIP_CONV8=w8 selects 8 (one row each)
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
@@ -644,7 +644,7 @@ const ActSpec kActs[] = {
     // decode: ystem (R0) -> d2 (R1) -> y4 (R2) -> x6 (R0, skip d2) -> voxels
     {"d_ystem", 64, 64, 0},    {"d_d2", 64, 64, 1},     {"d_y4", 64, 64, 2},     {"d_x6", 64, 64, 0},
     {"st_a.mean", 0, 8, -1},   {"st_a.rstd", 0, 8, -1}, {"st_b.mean", 0, 8, -1}, {"st_b.rstd", 0, 8, -1}, {"csum", 0, 64, -1}, {"gate", 0, 64, -1},
-    {"part_s", 0, 1024, -1},   {"part_q", 0, 1024, -1},  {"part_c", 0, 1024, -1},   // per-block statistics partials of split launches (fp64 x 512: 16 blocks x 16 slots, or 64 rows x 8 slots; fp32 x 1024)
+    {"part_s", 0, 1024, -1},   {"part_q", 0, 1024, -1},  {"part_c", 0, 1024, -1},   // per-block statistics partials of split launches (fp64 x 512: 16 blocks x 16 slots; fp32 x 1024); the 128 half-row partials of enc conv1 borrow e_a6
 };
 constexpr int kRegions = 3;
 
@@ -808,6 +808,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_dec_r64c1_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<false, true, 8, 0, true>, LDS_CONV8))) return rc;
+    if ((rc = set_lds(c, conv8_lds_k<false, true, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
@@ -896,13 +897,15 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
         const int gq = (2 * nt + 3) / 4;
-        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.grp_start = od("steps.rowgroups8_4"), A.part_s = ps, A.part_q = pq;
-        // conv1 carries the statistics: one range = one four-row group = one statistics block
+        // conv1 carries the statistics.  This tensor's statistics blocks are its 128 output half rows: 2 x 1024 doubles per leaf of
+        // partials, which live in the region of conv2's output (e_a6: free until conv2 runs, after the combine)
+        double* psr = reinterpret_cast<double*>(a["e_a6"]);
+        double* pqr = psr + (size_t)nt * 128 * 8 * 32;
+        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.grp_start = od("steps.rowgroups8_4"), A.part_s = psr, A.part_q = pqr;
         L.run("enc_res16_conv1_s", [&] {
             hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]);
         });
-        // (this tensor's statistics blocks are its 64 output rows)
-        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, ps, pq, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, psr, pqr, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
         // conv2 has none: a handful of tiles take two-row groups (32 ranges, half the serial chain per wave; same taps in the same order)
         const bool two = gq * 32 <= 512;   // up to 1024 leaves (measured)
         const char* tab = two ? "steps.rowgroups8_2" : "steps.rowgroups8_4";
@@ -992,12 +995,13 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rowgroups8_4"];
-        if (c->conv8_lds) {   // input planes staged in LDS by a persistent workgroup per CU; statistics as 64 row partials + combine
+        if (c->conv8_lds) {   // input planes staged in LDS by a persistent workgroup per CU; statistics as 16 half-row totals + combine
             A.part_s = reinterpret_cast<double*>(a["part_s"]), A.part_q = reinterpret_cast<double*>(a["part_q"]);
-            L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_lds_k<false, true, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
+            if (c->conv8_w16) L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_lds_k<false, true, 16, 0, false>), dim3(std::min(2 * nt, c->n_cus)), dim3(1024), LDS_CONV8, s, A); });
+            else L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_lds_k<false, true, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
             L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
-        } else {   // row-group kernel: one partial per output row, added row-major by the combine
-            A.part_s = reinterpret_cast<double*>(a["part_s"]), A.part_q = reinterpret_cast<double*>(a["part_q"]);
+        } else {   // row-group kernel: one partial per output half row (in the region of conv2's output, free until then), added row-major by the combine
+            A.part_s = reinterpret_cast<double*>(a["e_a6"]), A.part_q = A.part_s + (size_t)nt * 128 * 8 * 32;
             L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
             L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
         }
