@@ -1174,20 +1174,27 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
         f32x4 bq[MTL];   // this lane's bias quads, once per row (left in the expression below they are re-loaded for every position,
 #pragma unroll           // each load followed by s_waitcnt vmcnt(0): the stores in between may alias as far as the compiler knows)
         for (int mt = 0; mt < MTL; ++mt) bq[mt] = bias4[4 * (mz + mt) + q4];
+        // residual input: the loads of position ow+1 are in flight while position ow is finished (one exposed round trip per row
+        // instead of one per position)
+        f32x4 sk[RESID ? 2 : 1][RESID ? MTL : 1];
+        auto load_skip = [&](int ow) {
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) sk[ow & 1][mt] = buf_ld16(skb, lane_b + (mz + mt) * 2048, (unsigned)(row * SO + ow) * (COUT / 4) * 512u);
+        };
+        if (RESID) load_skip(0);
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow) {
             const size_t o = ((size_t)(row * SO + ow) * (COUT / 4)) * 32;
-            f32x4 sk[RESID ? MTL : 1];
-            if (RESID) {
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) sk[mt] = buf_ld16(skb, lane_b + (mz + mt) * 2048, (unsigned)(row * SO + ow) * (COUT / 4) * 512u);
+            if (RESID && ow + 1 < SO) {
+                load_skip(ow + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt) {
                 f32x4 v = acc[ow][mt] + bq[mt];
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
-                    v = sk[mt] + u;
+                    v = sk[ow & 1][mt] + u;
                 }
                 if (active) buf_st16_nt(v, outb, lane_b + (mz + mt) * 2048, (unsigned)(row * SO + ow) * (COUT / 4) * 512u);   // streaming store (see conv_first_k)
                 if (GOUT > 0) {
