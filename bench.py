@@ -57,6 +57,9 @@ def timed(fn, steps, dist, device):
 def profile_pass(codec, fn, steps, device):
     """Per-kernel averages from HIP events on the launch stream (library hook).  tflops_issued = FLOPs the kernel really
     executes on the matrix pipe / time; tflops_nominal_dense = dense FLOP count of the reference ops it replaces / time."""
+    for s in range(4):          # back to steady state first (the pass may follow the small-kernel training legs: clocks, caches)
+        fn(s)
+    torch.cuda.synchronize(device)
     codec.profile_enable(True)
     for s in range(steps):
         fn(s)
@@ -352,8 +355,8 @@ def main():
             full = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        ek = profile_pass(codec, enc, min(steps, 4), device)
-        dk = profile_pass(codec, dec, min(steps, 4), device)
+        ek = profile_pass(codec, enc, min(steps, 16), device)
+        dk = profile_pass(codec, dec, min(steps, 16), device)
         # spot parity: first 64 leaves of batch 0 vs the CPU oracle
         parity = None
         cpu = None
