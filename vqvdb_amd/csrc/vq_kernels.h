@@ -1315,6 +1315,8 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
     const int64_t leaf = (int64_t)tile * 32 + j;
     int p0 = 0, p1 = 64;
     if (gridDim.y > 1) p0 = (int)(blockIdx.y * 64 / gridDim.y), p1 = (int)((blockIdx.y + 1) * 64 / gridDim.y);
+    const bool packed = ((p0 | p1) & 3) == 0 && ((uintptr_t)A.idx & 3) == 0;   // (uniform)
+    unsigned pk = 0;
     f32x4 bn[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) bn[u] = in4[((size_t)p0 * 8 + 2 * u) * 32];
@@ -1380,7 +1382,16 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
         const float ob = __shfl_xor(best, 32, 64);
         const int ok = __shfl_xor(bk, 32, 64);
         if (ob < best || (ob == best && ok < bk)) bk = ok;
-        if (q == 0 && leaf < A.n_leaves) A.idx[leaf * 64 + p] = (uint8_t)bk;
+        // four consecutive positions of a leaf leave as one 32-bit store (a byte store per position touches 32 cache lines for 32 bytes)
+        if (packed) {
+            pk |= (unsigned)bk << (8 * (p & 3));
+            if ((p & 3) == 3) {
+                if (q == 0 && leaf < A.n_leaves) *(unsigned*)(A.idx + leaf * 64 + (p & ~3)) = pk;
+                pk = 0;
+            }
+        } else if (q == 0 && leaf < A.n_leaves) {
+            A.idx[leaf * 64 + p] = (uint8_t)bk;
+        }
     }
 }
 
