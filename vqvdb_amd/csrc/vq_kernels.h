@@ -428,9 +428,11 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
         }
     }
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
-    const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
-    f32x4* out4 = (f32x4*)A.out + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj;
-    const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 + q4 * 32 + jj : nullptr;
+    // buffer addressing (see buf_ld16): position p of this lane's channel quad
+    const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 512 * 4 * 32);
+    const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * 512 * 4 * 32);
+    const vq_buf skb = buf_of(RESID ? (const f32x4*)A.skip + (size_t)tile * 512 * 4 * 32 : (const f32x4*)A.out);
+    const unsigned lane_b = (unsigned)(q4 * 32 + jj) * 16u;
     GnAcc st[2];
     st[0].init();
     st[1].init();
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
     int4 en = steps[si + 1];
     f32x4 xr[8];
 #pragma unroll
-    for (int iw = 0; iw < 8; ++iw) xr[iw] = in4[((size_t)(e.x + iw) * 4) * 32];
+    for (int iw = 0; iw < 8; ++iw) xr[iw] = buf_ld16(inb, lane_b, (unsigned)(e.x + iw) * 2048u);
     for (int grp = g0; grp < g1; ++grp) {  // 8 od x (8/NR) row groups
         f32x4 acc[NR][8];
 #pragma unroll
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                         }
                     }
                 }
-                xr[iw] = in4[((size_t)(en.x + iw) * 4) * 32];  // next step's row (table index clamped)
+                xr[iw] = buf_ld16(inb, lane_b, (unsigned)(en.x + iw) * 2048u);  // next step's row (table index clamped)
             }
             last = (e.w & 2) != 0;
             e = en;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
             f32x4 sk[RESID ? 8 : 1];
             if (RESID) {
 #pragma unroll
-                for (int ow = 0; ow < 8; ++ow) sk[ow] = skip4[((size_t)(obase + rw * 8 + ow) * 4) * 32];
+                for (int ow = 0; ow < 8; ++ow) sk[ow] = buf_ld16(skb, lane_b, (unsigned)(obase + rw * 8 + ow) * 2048u);
             }
 #pragma unroll
             for (int ow = 0; ow < 8; ++ow) {
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
                     const f32x4 u = v * 0.1f;
                     v = sk[ow] + u;
                 }
-                out4[o] = v;
+                buf_st16(v, outb, lane_b, (unsigned)(obase + rw * 8 + ow) * 2048u);
                 if (STATS) {
                     st[0].add(v.x);
                     st[0].add(v.y);
