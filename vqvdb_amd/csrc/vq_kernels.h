@@ -1525,6 +1525,9 @@ struct StemFusedArgs {
     int n_tiles;
 };
 
+#ifndef STEM_DEPTH
+#define STEM_DEPTH 8
+#endif
 __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
 {
     __shared__ f32x4 ys[64 * 4 * 16];          // [pos][leaf 4][chunk 16]
@@ -1566,47 +1569,51 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
         const int g0 = wave * 8, g1 = g0 + 8;
         int si = A.grp_start[g0];
         const int NSm = A.n_steps - 1;
-        int4 e = A.steps[si], e1 = A.steps[min(si + 1, NSm)], e2 = A.steps[min(si + 2, NSm)], e3 = A.steps[min(si + 3, NSm)];
-#define STEMF_ROW(E) T4[((size_t)(E).y * 256 + my[(E).x]) * 16]
-        f32x4 r0 = STEMF_ROW(e), r1 = STEMF_ROW(e1), r2 = STEMF_ROW(e2), r3;
+        // D - 1 table rows in flight per wave (ring of D registers and D schedule entries, static indices).  The gather is bound by the
+        // L2 -> L1 path: 64 B/clk x ~700 ns of latency is ~100 KB in flight per CU; 16 waves x 3 rows x 1 KiB was half of that.
+        constexpr int D = STEM_DEPTH;
+        const vq_buf tb = buf_of(A.T);
+        // row of (tap, code): wave-uniform tap offset, lane offset = code row + this lane's 16-byte chunk
+        auto row = [&](const int4& E) -> f32x4 { return buf_ld16(tb, ((unsigned)my[E.x] * 64u + (unsigned)c * 4u) * 4u, (unsigned)E.y * 65536u); };
+        int4 ent[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) ent[i] = A.steps[min(si + i, NSm)];
+        f32x4 r[D];
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) r[i] = row(ent[i]);
         int po = g0;
         f32x4 acc = {0, 0, 0, 0};
         GnAcc st;
         st.init();
         bool done = false;
-        // (the wave's two block sums wait in registers: blk[0], blk[1])
-#define STEMF_STEP(RC, RN)                                                        \
-    if (!done) {                                                                  \
-        RN = STEMF_ROW(e3);                                                       \
-        const int4 e4 = A.steps[min(si + 4, NSm)];                                \
-        acc = acc + RC;                                                           \
-        const bool last = (e.w & 2) != 0;                                         \
-        e = e1, e1 = e2, e2 = e3, e3 = e4;                                        \
-        ++si;                                                                     \
-        if (last) {                                                               \
-            const f32x4 v = acc + b4;                                             \
-            ys[(po * 4 + l) * 16 + c] = v;                                        \
-            st.add(v.x);                                                          \
-            st.add(v.y);                                                          \
-            st.add(v.z);                                                          \
-            st.add(v.w);                                                          \
-            acc = (f32x4){0, 0, 0, 0};                                            \
-            if ((po & 3) == 3) {                                                  \
-                if (po & 4) bs1 = st.bs, bq1 = st.bq;                             \
-                else bs0 = st.bs, bq0 = st.bq;                                    \
-                st.init();                                                        \
-            }                                                                     \
-            done = ++po == g1;                                                    \
-        }                                                                         \
-    }
+        // (the wave's two block sums wait in registers: bs0/bq0, bs1/bq1)
         while (!done) {
-            STEMF_STEP(r0, r3)
-            STEMF_STEP(r1, r0)
-            STEMF_STEP(r2, r1)
-            STEMF_STEP(r3, r2)
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                if (!done) {
+                    r[(k + D - 1) % D] = row(ent[(k + D - 1) % D]);
+                    acc = acc + r[k];
+                    const bool last = (ent[k].w & 2) != 0;
+                    ent[k] = A.steps[min(si + D, NSm)];
+                    ++si;
+                    if (last) {
+                        const f32x4 v = acc + b4;
+                        ys[(po * 4 + l) * 16 + c] = v;
+                        st.add(v.x);
+                        st.add(v.y);
+                        st.add(v.z);
+                        st.add(v.w);
+                        acc = (f32x4){0, 0, 0, 0};
+                        if ((po & 3) == 3) {
+                            if (po & 4) bs1 = st.bs, bq1 = st.bq;
+                            else bs0 = st.bs, bq0 = st.bq;
+                            st.init();
+                        }
+                        done = ++po == g1;
+                    }
+                }
+            }
         }
-#undef STEMF_STEP
-#undef STEMF_ROW
     }
     // the 16 block sums in order, then low quad + high quad of the 8-channel group (lanes c and c ^ 1)
     float ia[4], ib[4];
