@@ -473,3 +473,27 @@ def test_denormal_and_tiny_inputs_match_oracle(codec, oracle):
     idx = codec.encode(leaves)
     assert np.array_equal(idx, oracle.encode(leaves, threads=4))
     assert np.array_equal(_bits(codec.decode(idx)), _bits(oracle.decode(idx, threads=4)))
+
+
+def test_large_path_kernel_variants_agree(pack, oracle, monkeypatch):
+    """The large-batch kernels have selectable variants (VQHIP_CONV8 = w8 | rows: 8-wave LDS-plane kernel / row-group kernel for the
+    16-channel convs instead of the 16-wave one; VQHIP_STEM=split: gather and GroupNorm as two kernels).  All of them implement the
+    same arithmetic contract: identical indices and voxels, and the oracle's on a sample."""
+    leaves = np.concatenate([synth.make_leaves(2200, seed=31), synth.edge_leaves()])
+    ref_idx = ref_rec = None
+    for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}):
+        for k in ("VQHIP_CONV8", "VQHIP_STEM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = HipCodec(pack)
+        c.set_small_batch_tiles(0)   # one wave (or workgroup) per tile: the kernels of full chunks, at any batch size
+        idx = c.encode(leaves)
+        rec = c.decode(idx)
+        c.close()
+        if ref_idx is None:
+            ref_idx, ref_rec = idx, rec
+            assert np.array_equal(idx[:256], oracle.encode(leaves[:256], threads=16))
+        else:
+            assert np.array_equal(idx, ref_idx), env
+            assert np.array_equal(_bits(rec), _bits(ref_rec)), env

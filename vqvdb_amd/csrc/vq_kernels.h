@@ -506,7 +506,6 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
             }
 #pragma unroll
             for (int ow = 0; ow < 8; ++ow) {
-                const size_t o = ((size_t)(obase + rw * 8 + ow) * 4) * 32;
                 f32x4 v = acc[rw][ow] + bias4;
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
@@ -699,7 +698,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 v.z = acc[mt][4 * g + 2] + bias.z;
                 v.w = acc[mt][4 * g + 3] + bias.w;
                 // regs 4g..4g+3 of half q hold couts 32mt + 8g + 4q + {0..3}: L4 group 8mt+2g+q
-                const size_t o = (((size_t)tile * NPO + po) * (COUT / 4) + 8 * mt + 2 * g + q) * 32 + j;
                 if (RESID) {
                     const f32x4 u = v * 0.1f;
                     v = skv[mt][g] + u;
@@ -911,7 +909,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32);
     const vq_buf skb = buf_of(RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 : (const f32x4*)A.out);
     f32x4* out4 = (f32x4*)A.out + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj;
-    const f32x4* skip4 = RESID ? (const f32x4*)A.skip + (size_t)tile * NPO * (COUT / 4) * 32 + q4 * 32 + jj : nullptr;
     const f32x4* bias4 = (const f32x4*)A.bias_frag;   // plain [COUT]: quad 4mt + q4
     const int NS = A.n_steps;
     int g0, g1;
@@ -1186,7 +1183,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
         if (RESID) load_skip(0);
 #pragma unroll
         for (int ow = 0; ow < SO; ++ow) {
-            const size_t o = ((size_t)(row * SO + ow) * (COUT / 4)) * 32;
             if (RESID && ow + 1 < SO) {
                 load_skip(ow + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1544,7 +1540,6 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
         sidx[tid >> 6][tid & 63] = leaf < A.n_leaves ? A.idx[leaf * 64 + (tid & 63)] : 0;
     }
     __syncthreads();
-    const f32x4* T4 = (const f32x4*)A.T + c;
     const f32x4 b4 = ((const f32x4*)A.bias)[c];
     const uint8_t* my = sidx[l];
 
