@@ -13,7 +13,7 @@ rows = db.execute("select kernel_name, grid_size_x, grid_size_y, counter_name, a
 d, best = {}, {}
 for k, gx, gy, c, v, dur in rows:   # per kernel keep the unsplit launches with the largest grid (the 65536-leaf ones)
     k = re.sub(r"\(.*", "", k).replace("void ", "")
-    if "at::" in k or "rocclr" in k or gy != 1 or gx < best.get(k, 0):
+    if "at::" in k or "rocclr" in k or gy > 2 or gx < best.get(k, 0):   # (gy = 2: the VQ search of full chunks)
         continue
     if gx > best.get(k, 0):
         best[k] = gx
