@@ -901,15 +901,17 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         // partials, which live in the region of conv2's output (e_a6: free until conv2 runs, after the combine)
         double* psr = reinterpret_cast<double*>(a["e_a6"]);
         double* pqr = psr + (size_t)nt * 128 * 8 * 32;
-        A.n_steps = c->nsteps["steps.rowgroups8_4"], A.grp_start = od("steps.rowgroups8_4"), A.part_s = psr, A.part_q = pqr;
-        L.run("enc_res16_conv1_s", [&] {
-            hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]);
-        });
-        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, psr, pqr, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
-        // conv2 has none: a handful of tiles take two-row groups (32 ranges, half the serial chain per wave; same taps in the same order)
+        // a handful of tiles take two-row groups (32 ranges, half the serial chain per wave; same taps in the same order) — both convs:
+        // the statistics blocks are half rows, whatever the row grouping
         const bool two = gq * 32 <= 512;   // up to 1024 leaves (measured)
         const char* tab = two ? "steps.rowgroups8_2" : "steps.rowgroups8_4";
-        A.n_steps = c->nsteps[tab], A.grp_start = od(tab), A.part_s = nullptr, A.part_q = nullptr;
+        A.n_steps = c->nsteps[tab], A.grp_start = od(tab), A.part_s = psr, A.part_q = pqr;
+        L.run("enc_res16_conv1_s", [&] {
+            if (two) hipLaunchKernelGGL((conv8_c16_k<2, false, true>), dim3(gq, 32), dim3(256), 0, s, A, (const int4*)w[tab]);
+            else hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w[tab]);
+        });
+        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, psr, pqr, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+        A.part_s = nullptr, A.part_q = nullptr;
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
         L.run("enc_res16_conv2_s", [&] {
