@@ -798,6 +798,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// The same folded tail on the 16x16x4 MFMA for the SMALLEST batches (a few tiles: SOP-sized calls): one wave = (tile, output slab d,
+// block of 16 voxels, 16-leaf half tile), sixteen waves per (tile, slab) instead of four.  Per output the arithmetic is the
+// 32x32x2 kernels' exactly — input positions ascending, channels in P8 order (8u, 8u+4, 8u+1, 8u+5 | 8u+2, 8u+6, 8u+3, 8u+7: two
+// MFMAs of four k steps per octet instead of four of two) — but a wave's serial chain is a quarter as long (K = 4 per 32-cycle
+// MFMA instead of K = 2 per 64), which is all that counts when a launch has fewer waves than the chip has SIMDs
+// (64-leaf decode: 90 -> ~30 us for this kernel).  Fragments: tail.w16[((step*8 + mb)*4 + uu)*64 + lane][e], octet u = 2uu + (e>>1),
+// MFMA mf = e&1, = Wc[voxel 16mb + (lane&15)][pos][8u + 4(k&1) + (k>>1) + 2mf], k = lane>>4; bias: plain per voxel.
+// Lane (leaf n = lane&15, k slot q4 = lane>>4) loads the channel quad 8u + 4(q4&1) of its leaf and feeds elements (q4>>1) and
+// 2 + (q4>>1) of it.  DEPTH positions of weights and activations in flight per wave (a position is only 16 MFMAs long).
+// ------------------------------------------------------------------------------------------
+template <int DEPTH = 4>
+__global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
+{
+    constexpr int CIN = 64, NPI = 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x, d = blockIdx.y, unit = blockIdx.z * 4 + wave;   // 16 units: 8 voxel blocks x 2 leaf halves
+    const int mb = unit >> 1, half = unit & 1;
+    const int n = lane & 15, q4 = lane >> 4, jj = 16 * half + n;
+    const int p0 = (d > 2 ? d - 2 : 0) * 16, p1 = ((d + 2 < 3 ? d + 2 : 3) + 1) * 16;   // 48 or 64 positions: multiples of DEPTH
+    const int sbase = d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176;                      // first step of slab d in tail.w16
+    static_assert(48 % DEPTH == 0 && 64 % DEPTH == 0, "whole rings");
+    float ta[8][2];   // attention gates of this lane's channels (computed once per tile by csum_combine_k)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) ta[u][mf] = A.se_gate[((size_t)tile * CIN + 8 * u + 4 * (q4 & 1) + (q4 >> 1) + 2 * mf) * 32 + jj];
+    const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32);
+    const unsigned lane_x = (unsigned)((q4 & 1) * 32 + jj) * 16u;
+    const vq_buf wb = buf_of(A.wfrag);
+    const unsigned lane_w = (unsigned)lane * 16u;
+    f32x4 w[DEPTH][4], b[DEPTH][8];
+    auto request = [&](int h, int p) {
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) w[h][uu] = buf_ld16(wb, lane_w, (unsigned)(((sbase - p0 + p) * 8 + mb) * 4 + uu) * 1024u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[h][u] = buf_ld16(inb, lane_x, (unsigned)(p * (CIN / 4) + 2 * u) * 512u);
+    };
+#pragma unroll
+    for (int h = 0; h < DEPTH; ++h) request(h, p0 + h);
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool hi = (q4 >> 1) != 0;
+    for (int p = p0; p < p1; p += DEPTH) {
+#pragma unroll
+        for (int h = 0; h < DEPTH; ++h) {
+            int pn = p + h + DEPTH < p1 ? p + h + DEPTH : p + h;   // the last ring re-requests valid data
+            asm volatile("" : "+s"(pn));   // opaque: keeps the loop-carried prefetch a prefetch
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 x = b[h][u], a = w[h][u >> 1];
+                const float x0 = (hi ? x.y : x.x) * ta[u][0], x1 = (hi ? x.w : x.z) * ta[u][1];
+                acc = mfma16((u & 1) ? a.z : a.x, x0, acc);
+                acc = mfma16((u & 1) ? a.w : a.y, x1, acc);
+            }
+            request(h, pn);
+            __builtin_amdgcn_sched_barrier(0);   // issue the refill here, not next to its use
+        }
+    }
+    const int64_t leaf = (int64_t)tile * 32 + jj;
+    if (leaf >= A.n_leaves) return;
+    const f32x4 bias = *(const f32x4*)(A.bias_frag + d * 128 + 16 * mb + 4 * q4);
+    f32x4 sg;
+    sg.x = vq_sigmoid(acc.x + bias.x);
+    sg.y = vq_sigmoid(acc.y + bias.y);
+    sg.z = vq_sigmoid(acc.z + bias.z);
+    sg.w = vq_sigmoid(acc.w + bias.w);
+    *(f32x4*)(A.out + leaf * 512 + d * 128 + 16 * mb + 4 * q4) = sg;   // 4 consecutive voxels of this lane's leaf
+}
+
+// ------------------------------------------------------------------------------------------
 // Row-blocked leaf-tile conv on the 16x16x4 MFMA for every layer with a 4^3 output: the decoder's ResidualBlock(64) convs
 // (VQVAE_v2.py:190-210, :260), the encoder's ResidualBlock(32) convs (:240) and the down conv 16->32 k4 s2 (:239).
 // A wave owns a 16-leaf HALF tile and one output row of SO = 4 positions (SO x COUT/16 accumulators of 16 couts x 16 leaves);

@@ -522,9 +522,26 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
         const std::vector<float> bfrag = dfrag32(bc.data() + d * 128, 128);
         bias.insert(bias.end(), bfrag.begin(), bfrag.end());
     }
+    // the same operator as 16x16x4 fragments for the smallest batches (tail_small16_k): [step][voxel block 8][uu 4][lane][e]
+    std::vector<float> frags16((size_t)224 * 8 * 4 * 64 * 4);
+    {
+        size_t step = 0;
+        for (int d = 0; d < 4; ++d)
+            for (int p = std::max(0, d - 2) * 16; p < (std::min(3, d + 2) + 1) * 16; ++p, ++step)
+                for (int mb = 0; mb < 8; ++mb)
+                    for (int uu = 0; uu < 4; ++uu)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int u = 2 * uu + (e >> 1), mf = e & 1, m = lane & 15, k = lane >> 4;
+                                const int ch = 8 * u + 4 * (k & 1) + (k >> 1) + 2 * mf;
+                                frags16[((((step * 8 + mb) * 4 + uu) * 64) + lane) * 4 + e] = wc[((size_t)(d * 128 + 16 * mb + m) * 64 + p) * 64 + ch];
+                            }
+    }
     int rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
+    if ((rc = upload(c, "tail.w16", frags16))) return rc;
+    if ((rc = upload(c, "tail.braw", bc))) return rc;
     return c->dw.count("steps.tail") ? VQHIP_OK : upload_steps(c, "steps.tail", steps);  // the schedule does not depend on the weights
 }
 
@@ -1112,7 +1129,14 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
         A.se_gate = a["gate"];   // computed once per tile by dec_csum_x6
-        L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small_k<false>, dim3(nt, 4), dim3(256), 0, s, A); });
+        // a few tiles: sixteen waves per (tile, slab) on the 16x16x4 MFMA (a quarter of the serial chain per wave)
+        static const int t16 = std::getenv("VQHIP_TAIL16_TILES") ? std::atoi(std::getenv("VQHIP_TAIL16_TILES")) : 48;   // measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us
+        if (nt <= t16) {
+            A.wfrag = w["tail.w16"], A.bias_frag = w["tail.braw"];
+            L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small16_k<4>, dim3(nt, 4, 4), dim3(256), 0, s, A); });
+        } else {
+            L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small_k<false>, dim3(nt, 4), dim3(256), 0, s, A); });
+        }
     }
     return L.rc;
 }
