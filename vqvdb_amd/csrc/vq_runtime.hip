@@ -785,8 +785,8 @@ constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, 
 constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (training forward, data gradients)
 constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
 // position-split inference launches: fused statistics as per-block partials (PARTS)
-constexpr auto k_dec_r64c1_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, true>;
-constexpr auto k_dec_r64c2_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, true>;
+constexpr auto k_dec_r64c1_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, true>;   // (kw-outer would spill here: the per-block statistics partials)
+constexpr auto k_dec_r64c2_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, true, 0, true>;   // kw-outer, register-staged weights: 309 -> 290 us at 4096 leaves
 constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, false, 0, true>;      // 8 waves, kw-outer with fragments read a group ahead    // weights LDS-resident
 constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, true>;   // position-split launches (8-wave workgroups), per-block partials
 constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 16, false, 0, true>;   // 16 waves behind one LDS copy (4/SIMD), kw-outer
@@ -802,6 +802,10 @@ constexpr size_t LDS_DEC_TAIL = (size_t)2 * (8 * 4 * 64) * 16;    // 2 x 32 KB
 // of a small batch): the 4^3 convs for the tiniest batches; the folded tail has its own small-batch kernel (tail_small_k)
 constexpr auto k_dec_r64c1_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 4, false, 8, true>;
 constexpr auto k_dec_r64c2_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 4, false, 8, true>;
+// ... with the quarter's weights of the whole layer LDS-resident (27 taps x 4 KB = 108 KB): no per-step barrier, no streaming
+constexpr auto k_dec_r64c1_rs4r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, true, 4, false, 8, true, 0, true>;
+constexpr auto k_dec_r64c2_rs4r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, true, 4, false, 8, true, 0, true>;
+constexpr size_t LDS_DEC_R64S4R = (size_t)27 * (4 * 1 * 64) * 16;
 constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 2, false, 8, true>;    // (statistics as per-block partials)
 constexpr auto k_enc_r32c1_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 2, false, 8, true>;
 constexpr auto k_enc_r32c2_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 2, false, 8, true>;
@@ -822,6 +826,8 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_dec_r64c2_r, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c1_rs, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rs, LDS_DEC_R64R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c1_rs4r, LDS_DEC_R64S4R))) return rc;
+    if ((rc = set_lds(c, k_dec_r64c2_rs4r, LDS_DEC_R64S4R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c1_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, k_dec_r64c2_rp, LDS_DEC_R64R))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<false, true, 8, 0, true>, LDS_CONV8))) return rc;
@@ -1109,8 +1115,10 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.part_s = ps, A.part_q = pq;
         const int gh = (2 * nt + 7) / 8, psr = split_factor(gh, 4, 16, 512);   // 8 half tiles per workgroup, 16 output rows to split
         const bool ms = gh * psr * 4 <= 1024;   // up to 2048 leaves (measured): also split the 64 couts over gridDim.z
+        static const bool r64res = !(std::getenv("VQHIP_R64S") && std::strcmp(std::getenv("VQHIP_R64S"), "stream") == 0);
         L.run("dec_res64_conv1_s", [&] {
-            if (ms) hipLaunchKernelGGL(k_dec_r64c1_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
+            if (ms && r64res) hipLaunchKernelGGL(k_dec_r64c1_rs4r, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64S4R, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else if (ms) hipLaunchKernelGGL(k_dec_r64c1_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_dec_r64c1_rp, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
         combine64("dec_stats_y4", a["st_a.mean"], a["st_a.rstd"]);
@@ -1118,7 +1126,8 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r64g2.w"], A.in_beta = w["r64g2.b"];
         A.part_s = nullptr, A.part_q = nullptr, A.part_c = a["part_c"];
         L.run("dec_res64_conv2_s", [&] {
-            if (ms) hipLaunchKernelGGL(k_dec_r64c2_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
+            if (ms && r64res) hipLaunchKernelGGL(k_dec_r64c2_rs4r, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64S4R, s, A, (const int4*)w["steps.rows_k3_4"]);
+            else if (ms) hipLaunchKernelGGL(k_dec_r64c2_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_dec_r64c2_rp, dim3(gh, psr), dim3(512), LDS_DEC_R64R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
         L.run("dec_csum_x6", [&] { hipLaunchKernelGGL((csum_combine_k<64>), dim3(nt), dim3(512), 0, s, a["part_c"], a["csum"], w["dfc0"], w["dfc2"], a["gate"]); });
