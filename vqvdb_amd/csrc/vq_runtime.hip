@@ -788,11 +788,11 @@ constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0,
 constexpr auto k_dec_r64c1_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, true>;   // (kw-outer would spill here: the per-block statistics partials)
 constexpr auto k_dec_r64c2_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, true, 0, true>;   // kw-outer, register-staged weights: 309 -> 290 us at 4096 leaves
 constexpr auto k_enc_down_r = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, false, 0, true>;      // 8 waves, kw-outer with fragments read a group ahead    // weights LDS-resident
-constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, true>;   // position-split launches (8-wave workgroups), per-block partials
+constexpr auto k_enc_down_rs = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 1, false, 8, true, 0, true>;   // position-split launches (8-wave workgroups), per-block partials
 constexpr auto k_enc_r32c1_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 16, false, 0, true>;   // 16 waves behind one LDS copy (4/SIMD), kw-outer
-constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 8, true>;
+constexpr auto k_enc_r32c1_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 1, false, 8, true, 0, true>;
 constexpr auto k_enc_r32c2_r = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, false, 16, false, 0, true>;
-constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, false, 8, true>;
+constexpr auto k_enc_r32c2_rs = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 1, false, 8, true, 0, true>;
 constexpr size_t LDS_ENC_DOWN_R = (size_t)64 * (1 * 2 * 64) * 16;   // 128 KB, resident
 constexpr size_t LDS_ENC_R32R = (size_t)27 * (2 * 2 * 64) * 16;     // 108 KB, resident
 constexpr size_t LDS_DEC_R64R = (size_t)2 * (3 * 16 * 64) * 16;      // 2 x 48 KB weight window
@@ -806,9 +806,9 @@ constexpr auto k_dec_r64c2_rs4 = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0
 constexpr auto k_dec_r64c1_rs4r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, true, 4, false, 8, true, 0, true>;
 constexpr auto k_dec_r64c2_rs4r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, true, 4, false, 8, true, 0, true>;
 constexpr size_t LDS_DEC_R64S4R = (size_t)27 * (4 * 1 * 64) * 16;
-constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 2, false, 8, true>;    // (statistics as per-block partials)
-constexpr auto k_enc_r32c1_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 2, false, 8, true>;
-constexpr auto k_enc_r32c2_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 2, false, 8, true>;
+constexpr auto k_enc_down_rs2 = conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true, 2, false, 8, true, 0, true>;    // (statistics as per-block partials)
+constexpr auto k_enc_r32c1_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true, 2, false, 8, true, 0, true>;
+constexpr auto k_enc_r32c2_rs2 = conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true, 2, false, 8, true, 0, true>;
 // position-split (small-batch) variants: 2 tiles per workgroup, no fused statistics
 
 constexpr size_t LDS_LATENT = (16 * 8 * 64 + 4 * 4 * 64) * 16;  // codebook + projection A-fragments (144 KB)
