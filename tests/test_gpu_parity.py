@@ -379,7 +379,7 @@ def test_in_process_multi_device_sharding(codec, pack):
 
 @pytest.mark.parametrize("n", [1, 64, 100, 300, 1024, 2048, 20000, 40000])
 def test_small_batch_split_path_is_bit_identical(pack, oracle, n):
-    """Position-split kernels with statistics fused as per-block partials (default policy: passes of <= 1800 tiles;
+    """Position-split kernels with statistics fused as per-block partials (default policy: passes of <= 1600 (encode) / 1728 (decode) tiles;
     the tiniest batches additionally split the output channels of the 4^3 convs, the folded tail has its own small-batch kernel) against the one-wave-per-tile path and the oracle: indices,
     every stored intermediate and voxels identical."""
     leaves = synth.make_leaves(n, seed=900 + n)

@@ -21,7 +21,7 @@ def t(fn, reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-for n in (2048, 4096, 8192, 12288, 16384, 24576, 32768, 49152, 57600, 65536):
+for n in (40960, 45056, 49152, 53248, 57344, 61440, 65536):
     reps = max(4, 200000 // n)
     row = [f"n={n:6d}"]
     for name, c in cs.items():

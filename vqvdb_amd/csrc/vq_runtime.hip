@@ -871,7 +871,7 @@ int split_factor(int wgs, int lo, int n_groups, int target)
 bool use_split(const vqhip_codec* c, int nt, bool decode)
 {
     if (c->split_tiles >= 0) return nt <= (decode ? 5 * c->split_tiles / 4 : c->split_tiles);
-    return nt <= 1800;   // both directions (57600 leaves)
+    return nt <= (decode ? 1728 : 1600);   // measured crossovers (r02 v8 kernels): encode 51 200 leaves, decode 55 296
 }
 
 // Small batches (too few leaf tiles to fill 1024 SIMDs with one wave per tile): every layer is launched with its output
