@@ -873,11 +873,14 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
 // A wave owns a 16-leaf HALF tile and one output row of SO = 4 positions (SO x COUT/16 accumulators of 16 couts x 16 leaves);
 // one step = (output row, valid (kd,kh)): the SI input positions of the row sit in a rolling register buffer (GroupNorm+ReLU
 // applied on arrival), each feeds its (ow,kw) pairs and is re-loaded for the next step right after its last use (k3: 6.25 row
-// loads per output row instead of 15.6 position loads per output position).  Weights: the KS kw-taps of the step stream
-// through a double-buffered LDS window by global_load_lds, shared by the 8 waves (4 tiles) of the workgroup, one barrier per
-// step (64->64: 640 MFMAs).  K order inside a tap: 16-channel blocks ascending, "P16" inside a block (0,4,8,12,1,5,...),
-// restated by the oracle for these layers.  Less HBM re-fetch also means a higher sustained clock: the 64->64 layers went from
-// 77 % pipe utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) to 83 % at 2.33 GHz (7 GB).
+// loads per output row instead of 15.6 position loads per output position).  Weights: LDS-resident where the layer's fragments
+// fit (RESIDENT), else the KS kw-taps of the step stream through a double-buffered LDS window shared by the 8 waves (4 tiles) of
+// the workgroup, one barrier per step (64->64: 640 MFMAs) — global -> register -> ds_write, one piece per MFMA group (REGW below),
+// in the kw-outer instantiations; by global_load_lds in the others (channel-split small-batch variants, training forwards).
+// K order inside a tap: 16-channel blocks ascending, "P16" inside a block (0,4,8,12,1,5,...), restated by the oracle for these
+// layers.  KWO: kw-outer MFMA order with the LDS fragments read a group ahead.  History of the 64->64 layers: 77 % pipe
+// utilisation at 2.13 GHz (one tap per step on the 32x32x2 MFMA, 17 GB fetched per launch) -> 83 % at 2.33 GHz (this kernel, 7 GB)
+// -> 91-93 % at 2.38 GHz (buffer addressing, REGW, lazy arrival).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0, bool KWO = false>
