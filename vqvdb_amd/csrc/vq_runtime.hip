@@ -782,8 +782,8 @@ constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, fals
 // large passes: kw-outer MFMA order (A fragments of a (kw, channel-block pair) read once for every output of the row)
 constexpr auto k_dec_r64c1_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, 0, true>;   // row-blocked 16x16x4 convs (4^3 outputs)
 constexpr auto k_dec_r64c2_r = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, false, 0, true>;
-constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false>;  // ... without fused statistics (training forward, data gradients)
-constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false>;
+constexpr auto k_dec_r64c1_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 0, false, false, 1, false, 8, false, 0, true>;  // ... without fused statistics (training forward, data gradients)
+constexpr auto k_dec_r64c2_rs = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, false, false, 1, false, 8, false, 0, true>;
 // position-split inference launches: fused statistics as per-block partials (PARTS)
 constexpr auto k_dec_r64c1_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, true>;   // (kw-outer would spill here: the per-block statistics partials)
 constexpr auto k_dec_r64c2_rp = conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false, 1, false, 8, true, 0, true>;   // kw-outer, register-staged weights: 309 -> 290 us at 4096 leaves
