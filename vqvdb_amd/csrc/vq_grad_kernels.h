@@ -336,6 +336,9 @@ struct WgradArgs {
     int n_tiles, tiles_per_group, KT;
 };
 
+#ifndef WGRAD_NS_OVERRIDE
+#define WGRAD_NS_OVERRIDE 0
+#endif
 template <int CIN, int COUT, int NPI, int NPO, int INMODE, int GIN>
 __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void wgrad32_k(WgradArgs A)
 {
@@ -344,15 +347,17 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     constexpr bool SMALL = CIN == 16;
     constexpr int CB = SMALL ? 1 : (COUT + 31) / 32, IB = SMALL ? 1 : (CIN + 31) / 32, NT = CB * IB * 64;
     constexpr int ROWS_DY = SMALL ? COUT : CB * 32, ROWS_X = SMALL ? 16 : IB * 32;
-    constexpr int NS = 1;   // position pairs staged per barrier (4 for the 16-channel layers was measured 2x SLOWER than 1)
+    // position pairs staged per pair of barriers.  One: two were measured 4-10 % SLOWER for the 32x32x2 layers (half the barriers, but
+    // twice the LDS footprint and a longer serial stage -> MFMA phase per workgroup), 4 for the 16-channel layers 2x slower.
+    constexpr int NS = WGRAD_NS_OVERRIDE > 0 ? WGRAD_NS_OVERRIDE : 1;
     // blocks in LDS as [leaf][channel] (round 2; [channel][leaf] before): a thread's float4 = 4 channels of one leaf goes in with ONE
     // 16-byte write instead of four scalar ones; the MFMA operands A[row = channel][k = leaf] are read row-wise over the channels
     // (consecutive banks).  Row stride +4 floats: the 32 leaves of a write land on 8 bank groups instead of one.
     constexpr int SDY = ROWS_DY + 4, SX = ROWS_X + 4;
-    __shared__ __attribute__((aligned(16))) float sdy[32][SDY];
-    __shared__ __attribute__((aligned(16))) float sx[32][SX];
-    for (int i = threadIdx.x; i < 32 * SDY; i += NT) (&sdy[0][0])[i] = 0.0f;
-    for (int i = threadIdx.x; i < 32 * SX; i += NT) (&sx[0][0])[i] = 0.0f;
+    __shared__ __attribute__((aligned(16))) float sdy[NS][32][SDY];
+    __shared__ __attribute__((aligned(16))) float sx[NS][32][SX];
+    for (int i = threadIdx.x; i < NS * 32 * SDY; i += NT) (&sdy[0][0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < NS * 32 * SX; i += NT) (&sx[0][0][0])[i] = 0.0f;
     const int tap = blockIdx.x, grp = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
     // the tap's (ip, po) pairs are cut into gridDim.z chunks (more workgroups for the small layers)
@@ -366,30 +371,34 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
 #pragma unroll
     for (int b = 0; b < (SMALL ? COUT / 16 : 1); ++b) acc16[b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
-    // One step = one (tile, position pair).  The step's dY / X blocks are requested one step AHEAD into registers (round 2): the loads
-    // of step k+1 are in flight while step k's MFMAs run; before, every step exposed a full L2 round trip between its two barriers.
-    static_assert(NS == 1, "one position pair per step");
+    // One GROUP = up to NS consecutive position pairs of one tile (a group never straddles tiles: the input transform is per tile).
+    // The group's dY / X blocks are requested one group AHEAD into registers: the loads of group g+1 are in flight while group g's
+    // MFMAs run.  Tile / group counters advance incrementally (no division by the run-time pair count in the loop).
     constexpr int ND = ((COUT / 4) * 32 + NT - 1) / NT, NX = ((CIN / 4) * 32 + NT - 1) / NT;
-    constexpr int PD = 1;   // prefetch distance in steps (3 measured no better: r64 layers -2 %, stem and r32 layers +10 %)
-    const int npairs = s1 - s0, nsteps = (t1 - t0) * npairs;
-    f32x4 rdy[PD][ND], rx[PD][NX];
+    const int npairs = s1 - s0, ngr = (npairs + NS - 1) / NS;
+    f32x4 rdy[NS][ND], rx[NS][NX];
+    int ft = t0, fg = 0;   // next group to request
     // (buffer addressing, see buf_ld16: the block of a position is one contiguous run, thread i takes float4 i)
-    auto fetch = [&](int k, f32x4 (&qdy)[ND], f32x4 (&qx)[NX]) {
-        if (k >= nsteps) return;   // (uniform)
-        const int tile = t0 + k / npairs;
-        const int2 e = A.wsteps[s0 + k % npairs];   // x = input position, y = output position
-        const vq_buf dyb = buf_of((const f32x4*)A.dy + (size_t)tile * NPO * (COUT / 4) * 32);
-        const vq_buf xb = buf_of((const f32x4*)A.x + (size_t)tile * NPI * (CIN / 4) * 32);
+    auto fetch_group = [&]() {
+        if (ft >= t1 || npairs <= 0) return;   // (uniform)
+        const vq_buf dyb = buf_of((const f32x4*)A.dy + (size_t)ft * NPO * (COUT / 4) * 32);
+        const vq_buf xb = buf_of((const f32x4*)A.x + (size_t)ft * NPI * (CIN / 4) * 32);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int i = threadIdx.x + d * NT;
-            if (i < (COUT / 4) * 32) qdy[d] = buf_ld16(dyb, (unsigned)i * 16u, (unsigned)e.y * (COUT / 4) * 512u);
-        }
+        for (int sl = 0; sl < NS; ++sl) {
+            if (fg * NS + sl >= npairs) continue;   // (uniform)
+            const int2 e = A.wsteps[s0 + fg * NS + sl];   // x = input position, y = output position
 #pragma unroll
-        for (int d = 0; d < NX; ++d) {
-            const int i = threadIdx.x + d * NT;
-            if (i < (CIN / 4) * 32) qx[d] = buf_ld16(xb, (unsigned)i * 16u, (unsigned)e.x * (CIN / 4) * 512u);
+            for (int d = 0; d < ND; ++d) {
+                const int i = threadIdx.x + d * NT;
+                if (i < (COUT / 4) * 32) rdy[sl][d] = buf_ld16(dyb, (unsigned)i * 16u, (unsigned)e.y * (COUT / 4) * 512u);
+            }
+#pragma unroll
+            for (int d = 0; d < NX; ++d) {
+                const int i = threadIdx.x + d * NT;
+                if (i < (CIN / 4) * 32) rx[sl][d] = buf_ld16(xb, (unsigned)i * 16u, (unsigned)e.x * (CIN / 4) * 512u);
+            }
         }
+        if (++fg == ngr) fg = 0, ++ft;
     };
     // the input transform of this thread's channels (GroupNorm scale / shift or attention gate): per (tile, channel, leaf), so it
     // changes only when the tile does — it used to be re-loaded in every step, 8-16 scalar loads per 16 MFMAs
@@ -414,52 +423,57 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
             }
         }
     };
-    // one step: blocks of step k (in registers) -> LDS ([leaf][channel], GroupNorm+ReLU / gate applied to X on the way), request step
-    // k + PD into the registers just freed, MFMAs
-    auto step = [&](int k, f32x4 (&qdy)[ND], f32x4 (&qx)[NX]) {
-        if (INMODE != 0 && k % npairs == 0) load_transform(t0 + k / npairs);   // (uniform)
-        __syncthreads();              // previous step's MFMAs have read the blocks
+    fetch_group();
+    int cg = 0;
+    for (int ct = t0; ct < t1 && npairs > 0;) {
+        // one group: its blocks (in registers) -> LDS ([leaf][channel], GroupNorm+ReLU / gate applied to X on the way), request the next
+        // group into the registers just freed, MFMAs pair by pair in ascending order
+        if (INMODE != 0 && cg == 0) load_transform(ct);   // (uniform)
+        const int nvalid = min(NS, npairs - cg * NS);
+        __syncthreads();              // previous group's MFMAs have read the blocks
 #pragma unroll
-        for (int dd = 0; dd < ND; ++dd) {
-            const int i = threadIdx.x + dd * NT;
-            if (i < (COUT / 4) * 32) *(f32x4*)&sdy[i & 31][4 * (i >> 5)] = qdy[dd];
-        }
+        for (int sl = 0; sl < NS; ++sl) {
+            if (sl >= nvalid) continue;   // (uniform)
 #pragma unroll
-        for (int dd = 0; dd < NX; ++dd) {
-            const int i = threadIdx.x + dd * NT;
-            if (i < (CIN / 4) * 32) {
-                const int quad = i >> 5, leaf = i & 31;
-                const f32x4 v = qx[dd];
-                float o[4] = {v.x, v.y, v.z, v.w};
+            for (int dd = 0; dd < ND; ++dd) {
+                const int i = threadIdx.x + dd * NT;
+                if (i < (COUT / 4) * 32) *(f32x4*)&sdy[sl][i & 31][4 * (i >> 5)] = rdy[sl][dd];
+            }
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (INMODE == 1) o[kk] = fmaxf(__builtin_fmaf(o[kk], tia[dd][kk], tib[dd][kk]), 0.0f);
-                    else if (INMODE == 2) o[kk] = o[kk] * tia[dd][kk];
+            for (int dd = 0; dd < NX; ++dd) {
+                const int i = threadIdx.x + dd * NT;
+                if (i < (CIN / 4) * 32) {
+                    const int quad = i >> 5, leaf = i & 31;
+                    const f32x4 v = rx[sl][dd];
+                    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (INMODE == 1) o[kk] = fmaxf(__builtin_fmaf(o[kk], tia[dd][kk], tib[dd][kk]), 0.0f);
+                        else if (INMODE == 2) o[kk] = o[kk] * tia[dd][kk];
+                    }
+                    *(f32x4*)&sx[sl][leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
                 }
-                *(f32x4*)&sx[leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
             }
         }
-        fetch(k + PD, qdy, qx);   // in flight during the next PD steps' MFMAs
+        if (++cg == ngr) cg = 0, ++ct;
+        fetch_group();   // in flight during this group's MFMAs
         __syncthreads();
-        if (SMALL) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const float bx = sx[4 * m + (lane >> 4)][lane & 15];
+        for (int sl = 0; sl < NS; ++sl) {
+            if (sl >= nvalid) continue;   // (uniform)
+            if (SMALL) {
 #pragma unroll
-                for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[4 * m + (lane >> 4)][16 * b + (lane & 15)], bx, acc16[b]);
+                for (int m = 0; m < 8; ++m) {
+                    const float bx = sx[sl][4 * m + (lane >> 4)][lane & 15];
+#pragma unroll
+                    for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[sl][4 * m + (lane >> 4)][16 * b + (lane & 15)], bx, acc16[b]);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    acc = mfma32(sdy[sl][2 * m + (lane >> 5)][32 * cb + (lane & 31)], sx[sl][2 * m + (lane >> 5)][32 * ib + (lane & 31)], acc);
             }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 16; ++m)
-                acc = mfma32(sdy[2 * m + (lane >> 5)][32 * cb + (lane & 31)], sx[2 * m + (lane >> 5)][32 * ib + (lane & 31)], acc);
         }
-    };
-#pragma unroll
-    for (int r = 0; r < PD; ++r) fetch(r, rdy[r], rx[r]);
-    for (int k = 0; k < nsteps; k += PD) {   // the register sets rotate with a static index
-#pragma unroll
-        for (int r = 0; r < PD; ++r)
-            if (k + r < nsteps) step(k + r, rdy[r], rx[r]);
     }
     float* dst = A.part + (((size_t)grp * gridDim.z + blockIdx.z) * A.KT + tap) * COUT * CIN;
     if (SMALL) {
