@@ -497,3 +497,23 @@ def test_large_path_kernel_variants_agree(pack, oracle, monkeypatch):
         else:
             assert np.array_equal(idx, ref_idx), env
             assert np.array_equal(_bits(rec), _bits(ref_rec)), env
+
+
+def test_small_path_kernel_variants_agree(pack, oracle, golden, monkeypatch):
+    """Small-batch decode has selectable variants too (VQHIP_TAIL16_TILES=0: folded tail on the 32x32x2 MFMA instead of 16x16x4;
+    VQHIP_R64S=stream: 64->64 convs with streamed instead of LDS-resident weights): same voxels bit for bit, and the oracle's."""
+    idx = np.concatenate([golden["idx_rand"][:300], golden["idx_edge"]])
+    ref = None
+    for env in ({}, {"VQHIP_TAIL16_TILES": "0"}, {"VQHIP_R64S": "stream"}):
+        for k in ("VQHIP_TAIL16_TILES", "VQHIP_R64S"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = HipCodec(pack)
+        rec = c.decode(idx)
+        c.close()
+        if ref is None:
+            ref = rec
+            assert np.array_equal(_bits(rec[:64]), _bits(oracle.decode(idx[:64], threads=16)))
+        else:
+            assert np.array_equal(_bits(rec), _bits(ref)), env

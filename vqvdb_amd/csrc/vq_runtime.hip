@@ -86,6 +86,9 @@ struct vqhip_codec {
     int64_t chunk = 65536;
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: stem_fused_k; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
+    int tail16_tiles = 48;   // small-batch folded tail on the 16x16x4 MFMA up to this many tiles (VQHIP_TAIL16_TILES; measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us)
+    bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
+    int vq_split = 2;        // position ranges per tile in the VQ search of full chunks (VQHIP_VQ_SPLIT)
     bool conv8_w16 = true;   // ... with 16 waves (one half row each; a half row is a statistics block); VQHIP_CONV8=w8 selects 8 (one row each)
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
@@ -1074,7 +1077,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
         // two position ranges per tile: 2 x n_tiles waves = 4 per SIMD on a full chunk (one wave per tile leaves 2, and the wave's
         // MFMA chain -> argmin scan -> next chain sequence has nobody to overlap with)
-        static const int vq_split = std::getenv("VQHIP_VQ_SPLIT") ? std::atoi(std::getenv("VQHIP_VQ_SPLIT")) : 2;
+        const int vq_split = c->vq_split;
         L.run("enc_vq", [&] { hipLaunchKernelGGL(vq_folded_k<8>, dim3(g8, vq_split), dim3(512), 0, s, A); });
     }
     return L.rc;
@@ -1115,7 +1118,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.part_s = ps, A.part_q = pq;
         const int gh = (2 * nt + 7) / 8, psr = split_factor(gh, 4, 16, 512);   // 8 half tiles per workgroup, 16 output rows to split
         const bool ms = gh * psr * 4 <= 1024;   // up to 2048 leaves (measured): also split the 64 couts over gridDim.z
-        static const bool r64res = !(std::getenv("VQHIP_R64S") && std::strcmp(std::getenv("VQHIP_R64S"), "stream") == 0);
+        const bool r64res = c->r64s_resident;
         L.run("dec_res64_conv1_s", [&] {
             if (ms && r64res) hipLaunchKernelGGL(k_dec_r64c1_rs4r, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64S4R, s, A, (const int4*)w["steps.rows_k3_4"]);
             else if (ms) hipLaunchKernelGGL(k_dec_r64c1_rs4, dim3(gh, psr, 4), dim3(512), LDS_DEC_R64R / 4, s, A, (const int4*)w["steps.rows_k3_4"]);
@@ -1139,7 +1142,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0, A.grp_start = od("steps.tail");
         A.se_gate = a["gate"];   // computed once per tile by dec_csum_x6
         // a few tiles: sixteen waves per (tile, slab) on the 16x16x4 MFMA (a quarter of the serial chain per wave)
-        static const int t16 = std::getenv("VQHIP_TAIL16_TILES") ? std::atoi(std::getenv("VQHIP_TAIL16_TILES")) : 48;   // measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us
+        const int t16 = c->tail16_tiles;
         if (nt <= t16) {
             A.wfrag = w["tail.w16"], A.bias_frag = w["tail.braw"];
             L.run("dec_tail_s", [&] { hipLaunchKernelGGL(tail_small16_k<4>, dim3(nt, 4, 4), dim3(256), 0, s, A); });
@@ -1510,6 +1513,9 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     }
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
+    if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
+    if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
+    if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
