@@ -65,5 +65,6 @@ int main()
     run("RESID, 8 waves, border-row loaders", conv8_lds_k<true, false, 8, 0, true>, A, cus, 512);
 #define RL(ABL) run("STATS, border-row loaders, ABL " #ABL, conv8_lds_k<false, true, 8, ABL, true>, A, cus, 512)
     RL(1); RL(4);
+    R(true, false, 16, 0); R(true, false, 16, 1); R(true, false, 16, 4); R(true, false, 16, 5); R(false, true, 16, 0); R(true, false, 16, 0);
     return 0;
 }

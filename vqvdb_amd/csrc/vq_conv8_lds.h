@@ -75,17 +75,23 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
         const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 512 * 4 * 32 + 16 * (hh & 1));
 #pragma unroll
         for (int k = 0; k < LPOS; ++k) pf[k] = buf_ld16(inb, lane_b, (unsigned)(id * 64 + lbase + k) * 2048u);
-        // channels 4q4 .. 4q4+3 -> GroupNorm(8,16) groups 2q4 (channels 0,1 of the quad) and 2q4+1 (channels 2,3)
-        pm0 = A.in_mean[((size_t)tile * 8 + 2 * q4) * 32 + jj], pr0 = A.in_rstd[((size_t)tile * 8 + 2 * q4) * 32 + jj];
-        pm1 = A.in_mean[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj], pr1 = A.in_rstd[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj];
+        // channels 4q4 .. 4q4+3 -> GroupNorm(8,16) groups 2q4 (channels 0,1 of the quad) and 2q4+1 (channels 2,3): the statistics
+        // change with the half tile only, so they travel with its first plane (they used to be re-loaded with every plane: four
+        // per-lane-pointer loads per wave and plane in a kernel whose staging costs 6 %)
+        if (id == 0) {   // (wave-uniform)
+            pm0 = A.in_mean[((size_t)tile * 8 + 2 * q4) * 32 + jj], pr0 = A.in_rstd[((size_t)tile * 8 + 2 * q4) * 32 + jj];
+            pm1 = A.in_mean[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj], pr1 = A.in_rstd[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj];
+        }
     };
+    float ia[4], ib[4];   // GroupNorm scale / shift of this lane's channel quad for the half tile being staged
     auto write_plane = [&](int P) {   // relu(GroupNorm(x)) once per element, then into slot P & 1
         if (!loader) return;   // (wave-uniform)
-        float ia[4], ib[4];
+        if ((P & 7) == 0) {   // (wave-uniform) first plane of a half tile: its statistics arrived with this plane's prefetch
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ia[i] = (i < 2 ? pr0 : pr1) * gam[i];
-            ib[i] = __builtin_fmaf(-(i < 2 ? pm0 : pm1), ia[i], bet[i]);
+            for (int i = 0; i < 4; ++i) {
+                ia[i] = (i < 2 ? pr0 : pr1) * gam[i];
+                ib[i] = __builtin_fmaf(-(i < 2 ? pm0 : pm1), ia[i], bet[i]);
+            }
         }
         f32x4* dst = slots + (P & 1) * 4096 + (lbase * 4 + q4) * 16 + j16;
 #pragma unroll
