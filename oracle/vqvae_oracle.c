@@ -83,7 +83,7 @@ enum { DBG_E_Y1, DBG_E_A1, DBG_E_Y4, DBG_E_A6, DBG_E_X7, DBG_E_Y9, DBG_E_X11, DB
 int vqo_tensor_count(void) { return W_COUNT; }
 int vqo_debug_count(void) { return DBG_COUNT; }
 
-/* ---- exp: identical operation sequence on CPU and GPU (vqvdb_amd/csrc/vq_math.h) ---- */
+/* ---- exp: identical operation sequence on CPU and GPU (vqvdb_amd/csrc/vq_device.h) ---- */
 static inline float vq_expf(float x)
 {
     if (x > 88.0f) x = 88.0f;
@@ -256,7 +256,12 @@ static void conv_tapsum(const float* in, float* out, const float* W, const float
  *   bc[ov]          = b_final + sum over valid dl ascending of Bg[dl][s']
  * Apply: per 128-voxel slab d (depths 2d,2d+1) the positions p = (pd,ph,pw), pd in [max(0,d-2),
  * min(3,d+2)], are visited in ascending order (weights that are structurally zero are still
- * multiplied: fmaf(0,x,acc)), channels in "P8" order; pre = acc + bc; out = sigmoid(pre). */
+ * multiplied: fmaf(0,x,acc)), channels in "P8" order.  ROW-BLOCKED accumulation (round 3): the four
+ * positions of a W-row (pd,ph,0..3) form one fmaf chain from zero (256 terms), the 12 or 16 row sums
+ * are added in row order with plain adds from zero; pre = acc + bc; out = sigmoid(pre).  One chain
+ * over all 3072-4096 terms (rounds 1-2) was 12x less accurate on a trained checkpoint, whose
+ * pre-activations reach +-20: |pre - fp64| 8.3e-5 against 1.5e-5 for the reference's own fp32
+ * evaluation; row-blocked: 6.6e-6 (tests/test_golden_regimes.py). */
 typedef struct {
     float* wc;  /* [512][64 pos][64 ci] */
     float bc[512];
@@ -322,16 +327,20 @@ static void tail_apply(const tail_t* T, const float* in /*[64][64][LT]*/, float*
     for (int ov = 0; ov < 512; ++ov) {
         const int d = ov >> 7;
         const int pd0 = d - 2 < 0 ? 0 : d - 2, pd1 = d + 2 > 3 ? 3 : d + 2;
-        float acc[LT];
-        for (int l = 0; l < LT; ++l) acc[l] = 0.0f;
+        float acc[LT], row[LT];
+        for (int l = 0; l < LT; ++l) acc[l] = 0.0f, row[l] = 0.0f;
         for (int p = pd0 * 16; p < (pd1 + 1) * 16; ++p) {
             const float* w = T->wc + (size_t)ov * 4096 + (size_t)p * 64;
+            if ((p & 3) == 0)                                   /* a new W-row of input positions: fresh chain */
+                for (int l = 0; l < LT; ++l) row[l] = 0.0f;
             for (int cc = 0; cc < 64; ++cc) {
                 const int ci = p8[cc];
                 const float wv = w[ci];
                 const float* x = in + ((size_t)ci * 64 + p) * LT;
-                for (int l = 0; l < LT; ++l) acc[l] = fmaf(wv, x[l], acc[l]);
+                for (int l = 0; l < LT; ++l) row[l] = fmaf(wv, x[l], row[l]);
             }
+            if ((p & 3) == 3)
+                for (int l = 0; l < LT; ++l) acc[l] = acc[l] + row[l];
         }
         for (int l = 0; l < LT; ++l) pre[(size_t)ov * LT + l] = acc[l] + T->bc[ov];
     }

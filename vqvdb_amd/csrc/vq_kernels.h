@@ -627,10 +627,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     __builtin_amdgcn_s_waitcnt(0x0f70);   // enter the loop with nothing in flight (see conv_rows16_k)
     for (int po = g0; po < g1; ++po) {
         f32x16 acc[NMT];
+        // OUTMODE 2 (folded tail): ROW-BLOCKED accumulation — the four input positions of a W-row (e.x = 4r .. 4r+3) are one fmaf
+        // chain from zero, the row sums are added in row order (oracle tail_apply).  One chain over all 3072-4096 terms was 12x less
+        // accurate on a trained checkpoint (pre-activations of +-20), tests/test_golden_regimes.py.
+        f32x16 tot[OUTMODE == 2 ? NMT : 1];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        if (OUTMODE == 2) {
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[mt][r] = 0.0f;
+        }
         bool last;
         do {
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];   // consumed one step later
@@ -673,11 +683,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     if (piece_first(g) + jp < piece_first(g + 1))
                         lds[((si + 1) & 1) * WSTEP + ((piece_first(g) + jp) * NW + wave) * 64 + lane] = wnext[jp];
             }
+            if (OUTMODE == 2 && (e.x & 3) == 3) {   // row complete (a slab's positions start and end on row boundaries)
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[mt][r] = tot[mt][r] + acc[mt][r], acc[mt][r] = 0.0f;
+            }
             last = (e.w & 2) != 0;
             e = en;
             en = en2;
             ++si;
         } while (!last);
+        if (OUTMODE == 2) {
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) acc[mt] = tot[mt];
+        }
 
         // ---- epilogue for output position po ----
         f32x4 skv[RESID ? NMT : 1][4];
@@ -751,9 +771,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             w[h][u] = w4[((size_t)(p0 + h) * NU + u) * NMT * 64];
             b[h][u] = in4[(size_t)(p0 + h) * (CIN / 4) * 32 + u * 64];
         }
-    f32x16 acc;
+    // row-blocked accumulation like conv_mfma32_k<OUTMODE 2>: the four positions of a W-row are one chain from zero (acc), the row
+    // sums are added in row order (tot)
+    f32x16 acc, tot;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f, tot[r] = 0.0f;
     for (int p = p0; p < p1; p += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -776,7 +798,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);   // issue the refill here, not where the scheduler would like it (next to its use)
             }
         }
+        if (p & 2) {   // second pair of a row (p0 is a multiple of 16)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[r] = tot[r] + acc[r], acc[r] = 0.0f;
+        }
     }
+    acc = tot;
     const f32x4* bf4 = (const f32x4*)A.bias_frag;
     const int64_t leaf = (int64_t)tile * 32 + j;
     if (!TILEOUT && leaf >= A.n_leaves) return;
@@ -838,7 +865,8 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
     };
 #pragma unroll
     for (int h = 0; h < DEPTH; ++h) request(h, p0 + h);
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    static_assert(DEPTH == 4, "one ring = one W-row of input positions = one accumulation block");
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, tot = {0.0f, 0.0f, 0.0f, 0.0f};   // row-blocked accumulation (see conv_mfma32_k<OUTMODE 2>)
     const bool hi = (q4 >> 1) != 0;
     for (int p = p0; p < p1; p += DEPTH) {
 #pragma unroll
@@ -855,7 +883,10 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
             request(h, pn);
             __builtin_amdgcn_sched_barrier(0);   // issue the refill here, not next to its use
         }
+        tot = tot + acc;
+        acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
+    acc = tot;
     const int64_t leaf = (int64_t)tile * 32 + jj;
     if (leaf >= A.n_leaves) return;
     const f32x4 bias = *(const f32x4*)(A.bias_frag + d * 128 + 16 * mb + 4 * q4);
