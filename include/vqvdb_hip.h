@@ -13,6 +13,12 @@
  *             [i*512,(i+1)*512) in OpenVDB leaf-buffer order (offset = d*64 + h*8 + w).
  *   indices : uint8   [n_leaves][64]   = Tensor shape [B,4,4,4]; position = d*16 + h*4 + w.
  *
+ * Non-finite voxels (policy): NaN / +-Inf / values whose activations overflow are not rejected — they propagate
+ * through the leaf that holds them exactly as in the reference's fp32 graph, and what that leaf encodes to is unspecified (some
+ * valid uint8 per position; torch.argmin of a NaN row is unspecified too).  Every OTHER leaf of the batch is unaffected bit for bit
+ * (no arithmetic mixes leaves; tests/test_gpu_parity.py::test_nan_inf_poison_stays_inside_its_own_leaf), and decode, whose input is
+ * indices, always returns finite voxels.
+ *
  * Every function returns VQHIP_OK (0) or a negative status; the message is available from
  * vqhip_last_error().  Nothing throws, nothing aborts.  A codec handle owns its device
  * buffers and streams; distinct handles may be used from distinct threads concurrently,

@@ -517,3 +517,55 @@ def test_small_path_kernel_variants_agree(pack, oracle, golden, monkeypatch):
             assert np.array_equal(_bits(rec[:64]), _bits(oracle.decode(idx[:64], threads=16)))
         else:
             assert np.array_equal(_bits(rec), _bits(ref)), env
+
+
+def test_nan_inf_poison_stays_inside_its_own_leaf(pack):
+    """SURVEY §8(c) F6 on the GPU (the oracle-level statement is tests/test_oracle_golden.py::test_nan_policy_is_propagation).
+    32 leaves share a tile and are the N dimension of every MFMA, GroupNorm partials of a tile sit in one buffer and the VQ
+    argmin is a compare/select scan — so: NaN, +Inf, -Inf and 3e38 voxels in leaves 5, 37 (second tile) and 64 (the ragged
+    tile's only leaf) of a 65-leaf batch must leave every OTHER leaf's indices and voxels bit-identical to the clean run, on
+    both launch paths and through decode.  What the poisoned leaves themselves encode to is reported, not pinned (the reference
+    propagates NaN and torch.argmin of a NaN row is unspecified; policy: include/vqvdb_hip.h)."""
+    leaves = synth.make_leaves(65, seed=21)
+    poisons = {"nan": np.float32(np.nan), "+inf": np.float32(np.inf), "-inf": np.float32(-np.inf), "3e38": np.float32(3e38)}
+    bad = [5, 37, 64]
+    keep = np.array([i for i in range(65) if i not in bad])
+    c = HipCodec(pack)
+    try:
+        for tiles in (-1, 0):                      # default policy (position-split at this size) / one wave per tile
+            c.set_small_batch_tiles(tiles)
+            clean_idx = c.encode(leaves)
+            clean_rec = c.decode(clean_idx)
+            for name, val in poisons.items():
+                x = leaves.copy()
+                x[5, 100] = val                      # one voxel
+                x[37, :] = val                       # a whole leaf
+                x[64, 0] = val
+                x[64, 511] = -val if name != "nan" else val
+                idx = c.encode(x)
+                assert np.array_equal(idx[keep], clean_idx[keep]), (tiles, name)
+                rec = c.decode(idx)                  # every uint8 is a valid code: decode cannot be poisoned, whatever the leaf encoded to
+                assert np.isfinite(rec).all(), (tiles, name)
+                assert np.array_equal(_bits(rec[keep]), _bits(clean_rec[keep])), (tiles, name)
+                print(f"path {'split' if tiles else 'wave/tile'} poison {name:4s}: leaf 5 -> {np.unique(idx[5]).size} distinct codes, leaf 37 -> codes {np.unique(idx[37])[:4]}, "
+                      f"leaf 64 -> {np.unique(idx[64]).size} distinct codes")
+    finally:
+        c.close()
+
+
+def test_decompress_the_file_the_reference_writer_wrote(codec):
+    """tests/golden/ref_writer_v3.vqvdb comes from the reference's REAL VDBStreamWriter (tools/prove_vqvdb_format.py; 2 grids,
+    ragged batches, non-identity transforms): vqhip_decompress_file returns its names / transforms / origins and, per leaf, the
+    decode of its indices."""
+    import os
+    from conftest import ROOT
+    from vqvdb_amd import vqvdbfile
+    path = os.path.join(ROOT, "tests", "golden", "ref_writer_v3.vqvdb")
+    want = vqvdbfile.load(path)
+    assert [len(g.origins) for g in want] == [700, 300]
+    for batch in (0, 97, 512):
+        grids, st = codec.decompress_file(path, batch_leaves=batch)
+        assert st["leaves"] == 1000 and st["grids"] == 2
+        for (name, tr, org, leaves), g in zip(grids, want):
+            assert name == g.name and np.array_equal(tr, g.transform) and np.array_equal(org, g.origins)
+            assert np.array_equal(_bits(leaves), _bits(codec.decode(g.indices)))

@@ -10,6 +10,7 @@
 //   leaf_harness decompress_stream <pack> <in.vqvdb>   <out.f32>   <batch>   (vqhip_decompress_file)
 //   leaf_harness errors     <pack>
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
+//   leaf_harness readcheck  <ref_writer_v3.vqvdb> <batch>   (no GPU needed: StreamReader over the file the reference's writer wrote)
 //   leaf_harness makefile   <out.vqvdb> <n_leaves> (synthetic indices; config-3 input)
 #define VQVDB_HIP_STANDALONE
 #include <chrono>
@@ -269,6 +270,39 @@ int streamtest(const std::string& path) {
 	return (grids == 2 && seen == 1000) ? 0 : 1;
 }
 
+// vqvdb::StreamReader over tests/golden/ref_writer_v3.vqvdb — written by the reference's REAL VDBStreamWriter
+// (src/Utils/VQVDB_Reader.cpp:58-150; generator tools/prove_vqvdb_format.py, which documents the content): 700 + 300 leaves
+int readcheck(const std::string& path, size_t batch) {
+	vqvdb::StreamReader r(path);
+	const char* names[2] = {"density", "temperature"};
+	const size_t counts[2] = {700, 300};
+	size_t base = 0;
+	int g = 0;
+	while (r.hasNextGrid()) {
+		const vqvdb::GridMeta m = r.nextGrid();
+		if (g > 1 || m.name != names[g] || m.totalBlocks != counts[g] || m.numEmbeddings != 256 || m.latentShape != std::vector<int64_t>{4, 4, 4}) return 10 + g;
+		if (m.transform[0] != 0.25f * (g + 1) || m.transform[13] != 3.0f * (g + 1) || m.transform[15] != 1.0f) return 20 + g;
+		std::vector<uint8_t> bi;
+		std::vector<vqvdb::Coord3i> bo;
+		size_t seen = 0;
+		while (r.hasNext()) {
+			const size_t n = r.nextBatch(batch, bi, bo);
+			for (size_t i = 0; i < n; ++i) {
+				const size_t j = base + seen + i;
+				if (bo[i].x != int32_t(j % 37) * 8 - 64 || bo[i].y != int32_t((j / 37) % 41) * 8 || bo[i].z != -int32_t(j / 1517) * 8) return 30 + g;
+				for (size_t k = 0; k < 64; ++k)
+					if (bi[i * 64 + k] != static_cast<uint8_t>(((j * 64 + k) * 2654435761u) >> 24)) return 40 + g;
+			}
+			seen += n;
+		}
+		if (seen != counts[g]) return 50 + g;
+		base += seen;
+		++g;
+	}
+	std::printf("readcheck: %d grids, %zu leaves, every field as the reference writer stored it\n", g, base);
+	return g == 2 ? 0 : 60;
+}
+
 int errors(const std::string& pack) {
 	int bad = 0;
 	auto expectThrow = [&](const char* what, auto&& fn, const char* msg) {
@@ -313,6 +347,7 @@ int main(int argc, char** argv) {
 		if (mode == "decompress_stream" && argc == 6) return decompressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "errors" && argc == 3) return errors(argv[2]);
 		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
+		if (mode == "readcheck" && argc == 4) return readcheck(argv[2], std::stoul(argv[3]));
 		if (mode == "makefile" && argc == 4) return makefile(argv[2], std::stoul(argv[3]));
 		std::fprintf(stderr, "usage: leaf_harness compress|decompress|errors ...\n");
 		return 2;
