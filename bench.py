@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 from vqvdb_amd import synth, weightpack  # noqa: E402
 from vqvdb_amd.codec import HipCodec  # noqa: E402
-from vqvdb_amd.sharding import bind_rank_to_cpus, max_over_ranks, usable_cpus  # noqa: E402
+from vqvdb_amd.sharding import bind_rank_to_cpus, gpu_numa_node, max_over_ranks, usable_cpus  # noqa: E402
 
 BATCH = 65536
 CONFIG3_LEAVES_PER_GPU = 8 * 1024 * 1024   # BASELINE configs[3]: 64 Mi leaves over 8 GPUs
@@ -216,8 +216,13 @@ def main():
     affinity = None
     if world > 1 and not rehearsal:
         try:
-            affinity = bind_rank_to_cpus(local, local_world, pci_bus_id=getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
-                                         pci_domain_id=getattr(torch.cuda.get_device_properties(device), "pci_domain_id", 0))
+            # NUMA node of EVERY local rank's GPU (local rank r drives device r), read from /sys by each rank itself: ranks that share a
+            # node then split it in rank order even when the GPU-to-node mapping is interleaved
+            props = [torch.cuda.get_device_properties(i) for i in range(min(local_world, torch.cuda.device_count()))]
+            nodes = [gpu_numa_node(getattr(p, "pci_bus_id", None), getattr(p, "pci_domain_id", 0)) for p in props]
+            affinity = bind_rank_to_cpus(local, local_world, pci_bus_id=getattr(props[local], "pci_bus_id", None),
+                                         pci_domain_id=getattr(props[local], "pci_domain_id", 0),
+                                         gpu_numa_nodes=nodes if len(nodes) == local_world and None not in nodes else None)
         except Exception as e:  # noqa: BLE001 — binding is an optimisation, never a reason to fail
             affinity = {"error": f"{type(e).__name__}: {e}"}
     if dist:
@@ -380,7 +385,7 @@ def main():
         out = {
             "metric": "8^3 leaves/s encode+quantize (decode reported under 'decode')",
             "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": round(t_enc / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(t_enc / steps * 1e3, 4), "timed_region_s": round(t_enc, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not cpu_rehearsal else "REHEARSAL on CPU with a stand-in codec: protocol test only, not a measurement",
             "config": {"workload": (f"BASELINE configs[1]: 1xMI355X, 1M synthetic leaves (16 x 65536-leaf batches, cycled for {steps} steps), fp32 encoder+quantizer, K=256 D=128" if world == 1 else
                                     f"BASELINE configs[3]: {world}xMI355X encode, leaves sharded across GPUs, {steps * BATCH} leaves per GPU "
@@ -395,7 +400,7 @@ def main():
             "roofline": roofline_of(ek, ENC_FLOP, enc_lps / world),
             "cpu_baseline": cpu,
             "decode": {
-                "value": round(dec_lps, 1), "unit": "leaves/s", "ms_per_step": round(t_dec / steps * 1e3, 4),
+                "value": round(dec_lps, 1), "unit": "leaves/s", "ms_per_step": round(t_dec / steps * 1e3, 4), "timed_region_s": round(t_dec, 4),
                 "workload": "decode of 65536-leaf index batches resident in HBM (kernel path of BASELINE configs[2]; the file-level run is under 'config3')",
                 "roofline": roofline_of(dk, DEC_FLOP, dec_lps / world),
             },
@@ -405,6 +410,7 @@ def main():
             "parity_sample": parity,
             "host_path": (host or {}).get("host_path") if host and "host_path" in host else host,
             "config3": (host or {}).get("config3"),
+            "orchestrator_loop": (host or {}).get("orchestrator_loop"),
             "host_process": (host or {}).get("process"),
             "codebook_training": train,
             "full_training": full,

@@ -149,8 +149,9 @@ int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_lea
 /* Leaves processed per internal pass (default 65536).  Bounds the device workspace
  * (about 0.1 MB per leaf for inference: three shared 32 KiB-per-leaf activation regions; 0.24 MB per leaf while
  * debug mode or the training entry points keep every intermediate).  If the device has less free memory than the chunk
- * needs (a GPU shared with a DCC application), the chunk is halved at the next call until it fits; results never depend
- * on the chunk size. */
+ * needs (a GPU shared with a DCC application), the chunk is halved until workspace + I/O slots fit into 80 % of the free memory:
+ * once, at the first host-pointer call (or vqhip_reserve) of the handle, and again at the call after a workspace allocation has
+ * failed with VQHIP_ERR_NOMEM (that call itself fails; the handle stays usable).  Results never depend on the chunk size. */
 int vqhip_set_chunk_leaves(vqhip_codec* codec, int64_t chunk_leaves);
 
 /* Small passes run the position-split kernels: each layer's output rows are spread over 4-16x more workgroups (the tiniest

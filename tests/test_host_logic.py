@@ -194,6 +194,16 @@ def test_rank_cpu_plan_is_a_partition():
     assert plan_rank_cpus([0, 1], 5, 8) == [0, 1]
     # NUMA node outside the allowed mask: falls back to the even split
     assert plan_rank_cpus(list(range(16)), 1, 2, list(range(64, 128)), 1, 0) == list(range(8, 16))
+    # an inconsistent slot (numa_slot >= numa_peers) never yields an empty set: even split
+    assert plan_rank_cpus(allowed, 5, 8, node1, 4, 4) == list(range(60, 72))
+    # interleaved GPU -> node mapping (even ranks on node 0, odd on node 1): with the gathered node list every rank gets its own slice
+    nodes = [r % 2 for r in range(8)]
+    node_cpus = {0: list(range(0, 48)), 1: node1}
+    sets = []
+    for r in range(8):
+        same = [q for q, nd in enumerate(nodes) if nd == nodes[r]]
+        sets.append(plan_rank_cpus(allowed, r, 8, node_cpus[nodes[r]], len(same), same.index(r)))
+    assert all(len(x) == 12 for x in sets) and sorted(sum(sets, [])) == allowed
 
 
 def test_hostbench_index_file_writer_matches_numpy_framing(tmp_path):

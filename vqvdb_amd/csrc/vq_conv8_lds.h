@@ -36,6 +36,7 @@ constexpr size_t LDS_CONV8 = (size_t)(27 * 64 + 2 * 4096) * 16;   // 155 648 B
 template <bool RESID, bool STATS, int NW = 8, int ABL = 0, bool LD2 = false>
 __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
 {
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
     static_assert(!LD2 || NW == 8, "border-row loaders: the 8-wave variant");
     static_assert(NW == 8 || NW == 16, "8 waves: one output row each; 16 waves: one half row (4 positions) each");
     constexpr int NT = NW * 64, OWN = 64 / NW;   // threads; output positions (and loader positions) per wave

@@ -21,6 +21,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VQ_LT 32  // leaves per tile
 
+// Timing-only ablation switches (template parameter ABL of conv8_lds_k / conv_rows16_k, the STEM_DEPTH / WGRAD_NS_OVERRIDE macros) exist
+// for tools/ablate/*.hip, which define VQ_ABLATE before including the kernel headers; a library build cannot instantiate them.
+#ifndef VQ_ABLATE
+#define VQ_ABLATE 0
+#if defined(STEM_DEPTH) || defined(WGRAD_NS_OVERRIDE)
+#error "STEM_DEPTH / WGRAD_NS_OVERRIDE are ablation switches: define VQ_ABLATE 1 (tools/ablate only)"
+#endif
+#endif
+
 // Buffer addressing for the activation traffic of the MFMA kernels: a wave-uniform base (descriptor in four SGPRs) + a wave-uniform
 // byte offset (one SGPR) + a per-lane byte offset that never changes (one VGPR).  The same access written as a per-lane 64-bit
 // pointer costs a 64-bit vector add per row and an address register PAIR per request, and each such global_load/global_store

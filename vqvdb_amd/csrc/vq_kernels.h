@@ -13,7 +13,6 @@
 
 struct ConvArgs {
     const float* in;         // L4 activations [tile][NPI][CIN/4][32][4]
-    const float* zeros;      // >= 64 bytes of zeros (first conv: operand of the K pad slot)
     float* out;              // L4 activations [tile][NPO][COUT/4][32][4] (or pixel-shuffled)
     const float* wfrag;      // fragment-ordered weights
     const float* bias_frag;  // bias in D-fragment order (mfma32) or plain (mfma16)
@@ -917,6 +916,7 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
 template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0, bool KWO = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
     // ABL: timing-only ablations for tools/ablate/conv_rows16_ablate.hip (0 in the library): 1 no barriers, 2 no weight streaming,
     // 4 no LDS A-fragment reads, 8 no activation re-loads, 16 no GroupNorm transform, 32 no epilogue, 64 every tile reads tile 0 (L2 hits)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -41,6 +41,73 @@ struct PackTensor {
     size_t count = 0;
 };
 
+// Name -> value table with a cheap lookup: every launch resolves its ~45 buffers by name (a["e_a1"], w["r16c1.w"]); as
+// std::map<std::string, ...> that was a heap of string constructions and tree walks per pass — measurable in the 0.14-0.2 ms
+// calls of SOP-sized batches.  Open addressing over an FNV-1a hash of the characters, no allocation on lookup; entries keep
+// their insertion order and their addresses' CONTENT stays put (values are only ever added), iteration yields .first / .second.
+template <typename T>
+struct NameMap {
+    struct Ent {
+        std::string first;
+        T second;
+    };
+    std::vector<Ent> ents;
+    std::vector<int> slots;   // index into ents, -1 = empty; size is a power of two > 2 * ents.size()
+    static uint32_t hash(const char* s)
+    {
+        uint32_t h = 2166136261u;
+        for (; *s; ++s) h = (h ^ (unsigned char)*s) * 16777619u;
+        return h;
+    }
+    int lookup(const char* s) const
+    {
+        if (slots.empty()) return -1;
+        const uint32_t mask = (uint32_t)slots.size() - 1;
+        for (uint32_t i = hash(s) & mask;; i = (i + 1) & mask) {
+            const int e = slots[i];
+            if (e < 0) return -1;
+            if (ents[e].first == s) return e;
+        }
+    }
+    void rehash()
+    {
+        size_t n = 64;
+        while (n < 4 * ents.size()) n *= 2;
+        slots.assign(n, -1);
+        for (size_t e = 0; e < ents.size(); ++e) {
+            uint32_t i = hash(ents[e].first.c_str()) & (uint32_t)(n - 1);
+            while (slots[i] >= 0) i = (i + 1) & (uint32_t)(n - 1);
+            slots[i] = (int)e;
+        }
+    }
+    T& operator[](const char* s)
+    {
+        int e = lookup(s);
+        if (e < 0) {
+            ents.push_back(Ent{s, T()});
+            e = (int)ents.size() - 1;
+            if (slots.size() < 4 * ents.size()) rehash();
+            else {
+                uint32_t i = hash(s) & (uint32_t)(slots.size() - 1);
+                while (slots[i] >= 0) i = (i + 1) & (uint32_t)(slots.size() - 1);
+                slots[i] = e;
+            }
+        }
+        return ents[e].second;
+    }
+    T& operator[](const std::string& s) { return (*this)[s.c_str()]; }
+    const Ent* find(const char* s) const { const int e = lookup(s); return e < 0 ? end() : &ents[e]; }
+    const Ent* find(const std::string& s) const { return find(s.c_str()); }
+    Ent* find(const char* s) { const int e = lookup(s); return e < 0 ? end() : &ents[e]; }
+    Ent* find(const std::string& s) { return find(s.c_str()); }
+    size_t count(const char* s) const { return lookup(s) >= 0; }
+    size_t count(const std::string& s) const { return lookup(s.c_str()) >= 0; }
+    Ent* begin() { return ents.data(); }
+    Ent* end() { return ents.data() + ents.size(); }
+    const Ent* begin() const { return ents.data(); }
+    const Ent* end() const { return ents.data() + ents.size(); }
+};
+
 struct KernelTimer {
     std::string name;
     hipEvent_t start, stop;
@@ -94,8 +161,8 @@ struct vqhip_codec {
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
     // device weights
-    std::map<std::string, float*> dw;
-    std::map<std::string, int> nsteps;
+    NameMap<float*> dw;
+    NameMap<int> nsteps;
     float e_final_bias = 0.0f;
 
     // workspace
@@ -104,15 +171,15 @@ struct vqhip_codec {
     bool chunk_fitted = false;
     char* ws = nullptr;
     size_t ws_bytes = 0;
-    std::map<std::string, float*> act;  // named activation buffers inside ws
-    std::map<std::string, std::pair<int, int>> act_shape;
+    NameMap<float*> act;  // named activation buffers inside ws
+    NameMap<std::pair<int, int>> act_shape;
 
     // host-pointer entry points: two I/O slots so H2D(i+1), compute(i) and D2H(i-1) overlap
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     void* pin_out[2] = {nullptr, nullptr};   // pinned landing zone for results (chunk * 2048 B each)
     void* pin_in[2] = {nullptr, nullptr};    // pinned gather buffers of the leaf-pointer entry points (lazy)
-    int64_t pin_in_leaves = 0;
+    size_t pin_in_bytes = 0;
     float* dev_leaves[2] = {nullptr, nullptr};  // chunk * 512 floats
     uint8_t* dev_idx[2] = {nullptr, nullptr};   // chunk * 64 bytes
     int64_t dev_io_leaves = 0;
@@ -620,7 +687,6 @@ int load_weights(vqhip_codec* c, const std::map<std::string, PackTensor>& pk)
     UP("ed.w16", frag16g(edw->data, 32, 16, 64)) UP("ed.braw", edb)
     UP("dfc0", dfc0) UP("dfc2", dfc2) if ((rc = build_folded_tail(c, duw->data, dub->data, dfw->data, dfb->data))) return rc;
     UP("cb", cb)
-    UP("zeros", std::vector<float>(64, 0.0f))   // operand of the first conv's K pad slot
     c->h_proj_w.assign(epw->data, epw->data + 128 * 32);
     c->h_proj_b.assign(epb->data, epb->data + 128);
     UP("tr.wproj", frag32(epw->data, 128, 32, 1)) UP("tr.bproj", dfrag32(epb->data, 128))
@@ -689,16 +755,31 @@ int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
     const int64_t tiles = (n_leaves + 31) / 32;
     const bool full = want_full_layout(c);
     if (tiles <= c->ws_tiles && (c->ws_full || !full)) return VQHIP_OK;   // a full layout also serves inference
-    const int64_t new_tiles = std::max(tiles, c->ws_tiles);
+    // growing within a layout keeps the larger size; a switch to the full layout (debug, training: 2.4x the bytes per leaf) is sized
+    // for what THIS call needs — a 32-leaf debug pass on a handle reserved for 65 536 leaves must not ask for 16 GB
+    int64_t new_tiles = (full && !c->ws_full) ? tiles : std::max(tiles, c->ws_tiles);
     if (c->ws) {
         HIPCHK(c, hipDeviceSynchronize());   // the workspace may be in use on a caller's stream
         HIPCHK(c, hipFree(c->ws));
         c->ws = nullptr;
         c->ws_tiles = 0;
+        c->ws_bytes = 0;
+        for (auto& kv : c->act) kv.second = nullptr;
     }
-    const size_t total = workspace_bytes(new_tiles, full);
+    size_t total = workspace_bytes(new_tiles, full);
     hipError_t e = hipMalloc(&c->ws, total);
-    if (e != hipSuccess) return fail(c, VQHIP_ERR_NOMEM, std::string("workspace hipMalloc of ") + std::to_string(total >> 20) + " MiB failed: " + hipGetErrorString(e));
+    if (e != hipSuccess && new_tiles > tiles) {   // the larger-than-needed size did not fit: what the call needs
+        new_tiles = tiles;
+        total = workspace_bytes(new_tiles, full);
+        e = hipMalloc(&c->ws, total);
+    }
+    if (e != hipSuccess) {
+        // the handle holds no workspace now (ws_bytes 0, every activation pointer null); the chunk is re-fitted to the free memory
+        // at the next host-pointer call, so a caller that retries after a transient shortage gets a smaller chunk instead of this error
+        c->ws = nullptr;
+        c->chunk_fitted = false;
+        return fail(c, VQHIP_ERR_NOMEM, std::string("workspace hipMalloc of ") + std::to_string(total >> 20) + " MiB failed: " + hipGetErrorString(e));
+    }
     c->ws_bytes = total;
     auto sz = [&](size_t per_leaf_floats) { return ((per_leaf_floats * sizeof(float) * 32 * (size_t)new_tiles) + 255) / 256 * 256; };
     size_t off = 0, region_off[kRegions] = {0, 0, 0};
@@ -898,7 +979,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         // mid-size batches: the first conv twice (statistics, then recompute + normalise + store), like the one-wave-per-tile path,
         // instead of storing its raw output and normalising it in an elementwise pass (2 x 32 KiB per leaf less traffic)
         ConvArgs A{};
-        A.in = a["xr"], A.zeros = w["zeros"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        A.in = a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         const int psf = split_factor(g4, 8, 16, 1024);
         L.run("enc_conv_first_stats_s", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
@@ -908,7 +989,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         combine("enc_stats_a1", 8, 1.0 / 1024.0, a["st_b.mean"], a["st_b.rstd"]);
     } else {
         ConvArgs A{};
-        A.in = a["xr"], A.zeros = w["zeros"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        A.in = a["xr"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         combine("enc_stats_y1", 4, 1.0 / 2048.0, a["st_a.mean"], a["st_a.rstd"]);
@@ -1010,7 +1091,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
-        A.in = a["xr"], A.zeros = w["zeros"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
+        A.in = a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
         A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
         L.run("enc_conv_first_stats", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
@@ -1237,17 +1318,17 @@ int ensure_io(vqhip_codec* c, int64_t n)
     return VQHIP_OK;
 }
 
-// pinned input staging (leaf blocks: gathered leaf buffers or the caller's pageable block)
-int ensure_stage(vqhip_codec* c, int64_t n)
+// pinned input staging (leaf blocks: gathered leaf buffers or the caller's pageable block; index blocks of single-chunk decodes)
+int ensure_stage(vqhip_codec* c, size_t bytes)
 {
-    if (c->pin_in_leaves >= n) return VQHIP_OK;
+    if (c->pin_in_bytes >= bytes) return VQHIP_OK;
     for (int i = 0; i < 2; ++i) {
         if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
         c->pin_in[i] = nullptr;
     }
-    c->pin_in_leaves = 0;
-    for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc(&c->pin_in[i], (size_t)n * 2048, hipHostMallocDefault));
-    c->pin_in_leaves = n;
+    c->pin_in_bytes = 0;
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc(&c->pin_in[i], bytes, hipHostMallocDefault));
+    c->pin_in_bytes = bytes;
     return VQHIP_OK;
 }
 
@@ -1344,7 +1425,29 @@ int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool w
     if (!rc) rc = ensure_io(c, step);
     if (rc) return rc;
     const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
-    if (want_stage && (rc = ensure_stage(c, step))) return rc;
+    if (want_stage && (rc = ensure_stage(c, (size_t)step * in_b))) return rc;
+    if (n <= step) {
+        // One chunk: there is nothing to overlap — H2D, kernels and D2H go down the compute stream in order and the call waits once.
+        // (The three-stream form below costs such a call three cross-stream event hand-overs and as many extra API calls: the SOP's
+        // default batch of 64 leaves is a 0.14-0.20 ms pass, so they showed: 0.26 / 0.21 ms per call through the adapter.)
+        void* d_in = is_encode ? (void*)c->dev_leaves[0] : (void*)c->dev_idx[0];
+        void* d_out = is_encode ? (void*)c->dev_idx[0] : (void*)c->dev_leaves[0];
+        const void* src = produce(0, n, want_stage ? c->pin_in[0] : nullptr);
+        if (!src) return c->err.empty() ? fail(c, VQHIP_ERR_INVALID, "input source failed") : VQHIP_ERR_INVALID;
+        auto sync_fail = [&](int code) {   // leave no copy in flight that references caller or slot memory
+            hipStreamSynchronize(c->stream);
+            return code;
+        };
+        hipError_t e = hipMemcpyAsync(d_in, src, (size_t)n * in_b, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return sync_fail(fail(c, VQHIP_ERR_DEVICE, std::string("hipMemcpyAsync H2D: ") + hipGetErrorString(e)));
+        rc = is_encode ? encode_chunk(c, c->dev_leaves[0], n, c->dev_idx[0], c->stream) : decode_chunk(c, c->dev_idx[0], n, c->dev_leaves[0], c->stream);
+        if (rc) return sync_fail(rc);
+        e = hipMemcpyAsync(c->pin_out[0], d_out, (size_t)n * out_b, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return sync_fail(fail(c, VQHIP_ERR_DEVICE, std::string("hipMemcpyAsync D2H: ") + hipGetErrorString(e)));
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(c, VQHIP_ERR_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        return consume(0, n, c->pin_out[0]);
+    }
     int64_t prev_off = -1, prev_m = 0;
     int prev_slot = 0, i = 0;
     auto drain = [&]() -> int {
@@ -1417,7 +1520,9 @@ int run_host_pipeline(vqhip_codec* c, bool is_encode, const void* in, void* out,
                       float* const* out_ptrs = nullptr)
 {
     const size_t in_b = is_encode ? 2048 : 64, out_b = is_encode ? 64 : 2048;
-    const bool stage_in = in_ptrs || (is_encode && n >= 4096);  // leaf blocks go through pinned staging (threads), not the pageable-copy path
+    // leaf blocks go through pinned staging (copied by threads when large), not the runtime's pageable-copy path; a call that fits one
+    // chunk stages whatever it gets (decode: 64 B per leaf) so that its H2D is an asynchronous copy on the compute stream
+    const bool stage_in = in_ptrs || (is_encode && n >= 4096) || n <= c->chunk;
     return run_pipeline(
         c, is_encode, n, 0, stage_in,
         [=](int64_t o, int64_t m, void* stage) -> const void* {
@@ -1598,7 +1703,7 @@ int vqhip_reserve(vqhip_codec* c, int64_t n)
     const int64_t m = std::min(n, c->chunk);
     int rc = ensure_workspace(c, m);
     if (!rc) rc = ensure_io(c, m);
-    if (!rc) rc = ensure_stage(c, m);
+    if (!rc) rc = ensure_stage(c, (size_t)m * 2048);
     return rc;
 }
 
@@ -2264,6 +2369,7 @@ int vqhip_debug_fetch(vqhip_codec* c, const char* name, int64_t n, float* out)
     auto it = c->act.find(name);
     if (it == c->act.end()) return fail(c, VQHIP_ERR_INVALID, std::string("debug_fetch: unknown activation '") + name + "'");
     const int C = c->act_shape[name].first, NP = c->act_shape[name].second;
+    if (std::strcmp(name, "xr") == 0) return fail(c, VQHIP_ERR_INVALID, "debug_fetch: 'xr' is the first conv's row layout [tile][64 rows][32 leaves][12], not a [tile][pos][32] activation; fetch 'xt'");
     if ((C != 1 && C < 4) || n > std::max(c->ws_tiles, c->ft_tiles) * 32) return fail(c, VQHIP_ERR_INVALID, "debug_fetch: not a tile activation or n too large");
     for (const ActSpec& a : kActs)   // compact (inference) layout: large activations share three regions and overwrite each other
         if (!c->ws_full && a.region != -1 && std::strcmp(a.name, name) == 0)

@@ -8,6 +8,7 @@
 //   leaf_harness decompress <pack> <in.vqvdb>   <out.f32>   <batch>
 //   leaf_harness compress_stream   <pack> <leaves.f32> <out.vqvdb> <batch>   (vqhip_compress_file: overlapped pipeline)
 //   leaf_harness decompress_stream <pack> <in.vqvdb>   <out.f32>   <batch>   (vqhip_decompress_file)
+//   leaf_harness loopbench  <pack> <n_leaves> <tmp.vqvdb> <batch>[,<batch>...]   (both loops, timed per phase, synthetic leaves)
 //   leaf_harness errors     <pack>
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
 //   leaf_harness readcheck  <ref_writer_v3.vqvdb> <batch>   (no GPU needed: StreamReader over the file the reference's writer wrote)
@@ -303,6 +304,113 @@ int readcheck(const std::string& path, size_t batch) {
 	return g == 2 ? 0 : 60;
 }
 
+// The reference orchestrator's two serial loops on synthetic leaves, timed per phase (bench.py -> "orchestrator_loop"):
+//   compress   (VQVAECodec.cpp:78-134):  per batch { fresh pack buffer + memcpy of the leaves | backend->encode | writeBatch }
+//   decompress (VQVAECodec.cpp:137-208): per batch { nextBatch | backend->decode (fresh zero-filled Tensor) | per-leaf memcpy into a 2 KiB leaf buffer }
+// One backend per batch size (the SOP node cache keeps it across cooks, SOP_VQVDB_Encoder.hpp:43-50); the first call of each
+// direction (lazy device allocations) is reported separately and excluded from the per-call figures, not from the totals.
+int loopbench(const std::string& pack, size_t total, const std::string& tmp, const std::string& batches) {
+	constexpr size_t BASE = 65536;
+	std::vector<float> base(std::min(total, BASE) * LEAF_VOXELS);
+	uint32_t x = 2463534242u;
+	for (float& v : base) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = static_cast<float>(x >> 8) * (1.0f / 16777216.0f); }
+	const size_t nbase = base.size() / LEAF_VOXELS;
+	std::vector<std::unique_ptr<float[]>> leafStore;   // decompress side: 2 KiB per leaf, allocated up front (the tree owns its leaves)
+	using clk = std::chrono::steady_clock;
+	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	size_t pos = 0;
+	while (pos < batches.size()) {
+		const size_t comma = batches.find(',', pos);
+		const size_t batch = std::stoul(batches.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos));
+		pos = comma == std::string::npos ? batches.size() : comma + 1;
+		auto backend = makeBackend(pack);
+		double tPack = 0, tCall = 0, tWrite = 0, first = 0;
+		size_t calls = 0;
+		const auto c0 = clk::now();
+		{
+			vqvdb::StreamWriter writer(tmp);
+			vqvdb::GridMeta meta;
+			meta.name = "density";
+			meta.latentShape = backend->getLatentShape();
+			meta.totalBlocks = total;
+			writer.startGrid(meta);
+			for (size_t start = 0; start < total; start += batch, ++calls) {
+				const size_t B = std::min(batch, total - start);
+				const auto t0 = clk::now();
+				std::vector<float> hostData(B * LEAF_VOXELS);
+				std::vector<vqvdb::Coord3i> origins(B);
+				for (size_t i = 0; i < B; ++i) {
+					origins[i] = originOf(start + i);
+					std::memcpy(hostData.data() + i * LEAF_VOXELS, base.data() + ((start + i) % nbase) * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
+				}
+				TensorView view;
+				view.data = hostData.data();
+				view.shape = {static_cast<int64_t>(B), 1, 8, 8, 8};
+				view.dtype = DataType::FLOAT32;
+				const auto t1 = clk::now();
+				const Tensor encoded = backend->encode(view);
+				const auto t2 = clk::now();
+				writer.writeBatch(encoded.getData<uint8_t>(), origins.data(), B);
+				const auto t3 = clk::now();
+				if (calls == 0) first = ms(t1, t2);
+				else tPack += ms(t0, t1), tCall += ms(t1, t2), tWrite += ms(t2, t3);
+			}
+			writer.endGrid();
+			writer.close();
+		}
+		const double wallC = ms(c0, clk::now());
+		const double nc = calls > 1 ? double(calls - 1) : 1.0;
+		std::printf("loopbench compress   batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: pack %.4f ms, encode %.4f ms, frame+write %.4f ms\n",
+		            batch, total, wallC, total / wallC / 1e3, first, tPack / nc, tCall / nc, tWrite / nc);
+		if (leafStore.empty()) {
+			leafStore.resize((total + BASE - 1) / BASE);
+			for (size_t i = 0; i < leafStore.size(); ++i) { leafStore[i].reset(new float[BASE * LEAF_VOXELS]); std::memset(leafStore[i].get(), 0, BASE * LEAF_VOXELS * sizeof(float)); }
+		}
+		double tRead = 0, tDec = 0, tCopy = 0;
+		first = 0, calls = 0;
+		size_t leafNo = 0;
+		const auto d0 = clk::now();
+		{
+			vqvdb::StreamReader reader(tmp);
+			while (reader.hasNextGrid()) {
+				const vqvdb::GridMeta meta = reader.nextGrid();
+				std::vector<uint8_t> idx;
+				std::vector<vqvdb::Coord3i> origins;
+				while (reader.hasNext()) {
+					const auto t0 = clk::now();
+					const size_t B = reader.nextBatch(batch, idx, origins);
+					if (B == 0) break;
+					TensorView view;
+					view.data = idx.data();
+					view.shape = {static_cast<int64_t>(B)};
+					view.shape.insert(view.shape.end(), meta.latentShape.begin(), meta.latentShape.end());
+					view.dtype = DataType::UINT8;
+					const auto t1 = clk::now();
+					const Tensor decoded = backend->decode(view);
+					const auto t2 = clk::now();
+					const float* src = decoded.getData<float>();
+					for (size_t i = 0; i < B; ++i) {  // stand-in for touchLeaf + memcpy + setValuesOn (VQVAECodec.cpp:182-192)
+						const size_t j = leafNo + i;
+						std::memcpy(leafStore[j / BASE].get() + (j % BASE) * LEAF_VOXELS, src + i * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
+					}
+					const auto t3 = clk::now();
+					if (calls == 0) first = ms(t1, t2);
+					else tRead += ms(t0, t1), tDec += ms(t1, t2), tCopy += ms(t2, t3);
+					leafNo += B;
+					++calls;
+				}
+			}
+		}
+		const double wallD = ms(d0, clk::now());
+		const double nd = calls > 1 ? double(calls - 1) : 1.0;
+		std::printf("loopbench decompress batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: read+deframe %.4f ms, decode %.4f ms, leaf copies %.4f ms\n",
+		            batch, leafNo, wallD, leafNo / wallD / 1e3, first, tRead / nd, tDec / nd, tCopy / nd);
+		if (leafNo != total) return 1;
+	}
+	std::remove(tmp.c_str());
+	return 0;
+}
+
 int errors(const std::string& pack) {
 	int bad = 0;
 	auto expectThrow = [&](const char* what, auto&& fn, const char* msg) {
@@ -346,6 +454,7 @@ int main(int argc, char** argv) {
 		if (mode == "compress_stream" && argc == 6) return compressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "decompress_stream" && argc == 6) return decompressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "errors" && argc == 3) return errors(argv[2]);
+		if (mode == "loopbench" && argc == 6) return loopbench(argv[2], std::stoul(argv[3]), argv[4], argv[5]);
 		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
 		if (mode == "readcheck" && argc == 4) return readcheck(argv[2], std::stoul(argv[3]));
 		if (mode == "makefile" && argc == 4) return makefile(argv[2], std::stoul(argv[3]));

@@ -13,6 +13,11 @@ such a process — so bench.py runs these legs here, as a child, and embeds the 
               allocator (here: consecutive 2 KiB slots of one pre-touched pool — the cheapest possible `touchLeaf`; the C++
               harness leg with a hash-map leaf store is reported beside it when the harness binary is present).
               Reference path replaced: src/orchestrator/VQVAECodec.cpp:137-208, src/Utils/VQVDB_Reader.cpp:240-335.
+  orchestrator_loop : what a drop-in user of the KEPT orchestrator gets — the reference's two serial loops
+              (VQVAECodec.cpp:78-134 compress, :137-208 decompress: IVQVAECodec::create -> per batch {fresh buffer -> TensorView ->
+              encode/decode -> owning Tensor -> framing / per-leaf copies}) through the C++ adapter, 1 Mi leaves at the SOP's batch
+              sizes (64 default, 1024 = encoder maximum, 8192 = decoder maximum; SOP_VQVDB_Encoder.cpp:33-38) and at 65536,
+              with the per-call time split into its phases (`leaf_harness loopbench`).
 """
 from __future__ import annotations
 
@@ -50,6 +55,39 @@ def write_index_file(path: str, indices_fn, n: int, chunk: int = 1 << 20, name: 
             rec["origin"] = origins_of(m, s)
             rec["indices"] = indices_fn(s, m)
             f.write(rec.tobytes())
+
+
+LOOP_RE = re.compile(r"loopbench (compress|decompress)\s+batch (\d+): (\d+) leaves in ([\d.]+) ms = ([\d.]+) M leaves/s \| first call ([\d.]+) ms \| "
+                     r"per call: [\w+]+ ([\d.]+) ms, (?:encode|decode) ([\d.]+) ms, [\w+ ]+ ([\d.]+) ms")
+
+
+def orchestrator_loop(harness: str, W: dict, tmpdir: str, n: int, batches=(64, 1024, 8192, 65536)) -> dict:
+    """`leaf_harness loopbench`: the reference orchestrator's serial compress / decompress loops through the adapter."""
+    with tempfile.NamedTemporaryFile(suffix=".vqw", delete=False) as f:
+        f.write(weightpack.dumps(W))
+        pk = f.name
+    tmp = os.path.join(tmpdir, f"vqhip_loop_{os.getpid()}.vqvdb")
+    res = {"workload": f"{n} leaves per leg; reference call sequence (VQVAECodec.cpp:78-134,137-208) through IVQVAECodec::create + HipBackend, serial, "
+                       "pageable host buffers, a fresh pack buffer / zero-filled Tensor per batch; batch sizes: SOP default 64, encoder max 1024, decoder max 8192 "
+                       "(SOP_VQVDB_Encoder.cpp:33-38), and the backend's chunk 65536",
+           "leaves": n, "batches": {}}
+    try:
+        r = subprocess.run([harness, "loopbench", pk, str(n), tmp, ",".join(str(b) for b in batches)], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        for m in LOOP_RE.finditer(r.stdout):
+            leg, b = m.group(1), m.group(2)
+            names = ("pack_ms", "encode_ms", "frame_write_ms") if leg == "compress" else ("read_deframe_ms", "decode_ms", "leaf_copy_ms")
+            res["batches"].setdefault(b, {})[leg] = {
+                "leaves_per_s": round(float(m.group(5)) * 1e6, 1), "wall_s": round(float(m.group(4)) / 1e3, 4), "first_call_ms": float(m.group(6)),
+                "per_call": dict(zip(names, (float(m.group(7)), float(m.group(8)), float(m.group(9)))))}
+        if not res["batches"]:
+            return {"error": "no loopbench lines parsed: " + r.stdout[-300:]}
+    finally:
+        os.unlink(pk)
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return res
 
 
 def run(args) -> dict:
@@ -127,6 +165,8 @@ def run(args) -> dict:
             finally:
                 os.unlink(pk)
         out["config3"] = c3
+        if os.path.exists(harness) and not args.no_harness and args.loop_leaves > 0:
+            out["orchestrator_loop"] = orchestrator_loop(harness, W, tmpdir, args.loop_leaves)
     finally:
         if os.path.exists(path):
             os.unlink(path)
@@ -142,6 +182,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-harness", action="store_true")
+    ap.add_argument("--loop-leaves", type=int, default=1 << 20, help="leaves per orchestrator_loop leg (0 = skip)")
     args = ap.parse_args(argv)
     assert "torch" not in sys.modules, "hostbench must run without PyTorch in the process"
     res = run(args)

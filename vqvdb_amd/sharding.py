@@ -99,7 +99,7 @@ def plan_rank_cpus(allowed: list, local_rank: int, local_world: int, numa_cpus: 
     same node (this rank being number `numa_slot` of them).  Otherwise: an even contiguous split of the allowed CPUs over the
     local ranks.  Never returns an empty set: with fewer CPUs than ranks the whole allowed set is kept (no binding)."""
     allowed = sorted(allowed)
-    if numa_cpus:
+    if numa_cpus and 0 <= numa_slot < numa_peers:      # an inconsistent slot falls through to the even split (never an empty set)
         pool = [c for c in sorted(numa_cpus) if c in set(allowed)]
         if len(pool) >= numa_peers >= 1:
             per = len(pool) // numa_peers
@@ -110,27 +110,40 @@ def plan_rank_cpus(allowed: list, local_rank: int, local_world: int, numa_cpus: 
     return allowed[local_rank * per:(local_rank + 1) * per]
 
 
+def gpu_numa_node(pci_bus_id, pci_domain_id: int = 0) -> Optional[int]:
+    """NUMA node of the GPU at (domain, bus) from /sys, None when the topology is not exposed."""
+    if pci_bus_id is None:
+        return None
+    try:
+        node = int(open(f"/sys/bus/pci/devices/{int(pci_domain_id):04x}:{int(pci_bus_id):02x}:00.0/numa_node").read())
+        return node if node >= 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def bind_rank_to_cpus(local_rank: int, local_world: int, pci_bus_id=None, pci_domain_id: int = 0, gpu_numa_nodes: Optional[list] = None) -> dict:
     """Pin this process (and the library's copy threads it will spawn) to its share of the host cores: the cores of the GPU's
-    NUMA node when /sys exposes it, an even split otherwise.  gpu_numa_nodes: NUMA node of every local rank's GPU, if the
-    caller gathered them (lets ranks that share a node split it); without it each rank takes its node's cores divided by
-    ceil(local_world / number of nodes).  Returns what was done (for the bench JSON)."""
+    NUMA node when /sys exposes it, an even split otherwise.  gpu_numa_nodes: NUMA node of every local rank's GPU (bench.py reads
+    them for all local devices with gpu_numa_node — no collective needed): the ranks whose GPUs share a node split it in rank
+    order, whatever the GPU-to-node mapping looks like (interleaved mappings included).  Without it each rank takes its node's
+    cores divided by ceil(local_world / number of nodes), which is collision-free only when the ranks of a node are consecutive.
+    A list that disagrees with this rank's own /sys reading is ignored (even split).  Returns what was done (for the bench JSON)."""
     import os
     allowed = sorted(os.sched_getaffinity(0))
-    node, numa_cpus = None, None
-    if pci_bus_id is not None:
+    node, numa_cpus = gpu_numa_node(pci_bus_id, pci_domain_id), None
+    if node is not None:
         try:
-            dev = f"{int(pci_domain_id):04x}:{int(pci_bus_id):02x}:00.0"
-            node = int(open(f"/sys/bus/pci/devices/{dev}/numa_node").read())
-            if node >= 0:
-                numa_cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+            numa_cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
         except (OSError, ValueError):
             node, numa_cpus = None, None
     peers, slot = 1, 0
     if numa_cpus:
         if gpu_numa_nodes:
             same = [r for r, nd in enumerate(gpu_numa_nodes) if nd == node]
-            peers, slot = len(same), same.index(local_rank)
+            if local_rank in same:
+                peers, slot = len(same), same.index(local_rank)
+            else:                                   # the list contradicts this rank's own reading: do not trust either
+                numa_cpus = None
         else:
             try:
                 n_nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
@@ -144,4 +157,5 @@ def bind_rank_to_cpus(local_rank: int, local_world: int, pci_bus_id=None, pci_do
         os.sched_setaffinity(0, cpus)
         bound = True
     return {"bound": bound, "cpus_bound": len(cpus), "first_cpu": cpus[0] if cpus else None, "numa_node": node,
+            "numa_peers": peers if numa_cpus else None, "numa_slot": slot if numa_cpus else None,
             "policy": "GPU's NUMA node" if numa_cpus else "even split of the allowed CPUs"}
