@@ -254,9 +254,10 @@ static void conv_tapsum(const float* in, float* out, const float* W, const float
  *                     neighbour z = ov + dl - 1 lies in 4^3 cell c' = z/2 with sub-position s' = z%2 and
  *                     t is the up_conv tap with p = c' + t - 1                    (plain fp64 adds from 0)
  *   bc[ov]          = b_final + sum over valid dl ascending of Bg[dl][s']
- * Apply: per 128-voxel slab d (depths 2d,2d+1) the positions p = (pd,ph,pw), pd in [max(0,d-2),
- * min(3,d+2)], are visited in ascending order (weights that are structurally zero are still
- * multiplied: fmaf(0,x,acc)), channels in "P8" order.  ROW-BLOCKED accumulation (round 3): the four
+ * Apply: per output voxel of depth plane od the positions p = (pd,ph,pw) of the input planes pd it can
+ * depend on (pd_lo(od) .. pd_hi(od), two levels of 3-tap reach: 2, 3 or 4 planes) are visited in ascending
+ * order — all 16 (ph,pw) of such a plane, weights that are structurally zero inside it are still multiplied:
+ * fmaf(0,x,acc) — channels in "P8" order.  ROW-BLOCKED accumulation (round 3): the four
  * positions of a W-row (pd,ph,0..3) form one fmaf chain from zero (256 terms), the 12 or 16 row sums
  * are added in row order with plain adds from zero; pre = acc + bc; out = sigmoid(pre).  One chain
  * over all 3072-4096 terms (rounds 1-2) was 12x less accurate on a trained checkpoint, whose
@@ -325,8 +326,11 @@ static void tail_apply(const tail_t* T, const float* in /*[64][64][LT]*/, float*
     int p8[64];
     korder_p8(64, p8);
     for (int ov = 0; ov < 512; ++ov) {
-        const int d = ov >> 7;
-        const int pd0 = d - 2 < 0 ? 0 : d - 2, pd1 = d + 2 > 3 ? 3 : d + 2;
+        /* input depth planes voxel plane od depends on: final taps reach z = od-1 .. od+1 (inside 0..7), z lies in coarse cell z/2,
+         * the up conv's taps reach cell-1 .. cell+1 (inside 0..3); the composite weights of every other plane are structurally zero */
+        const int od = ov >> 6;
+        const int c0 = (od > 0 ? od - 1 : 0) >> 1, c1 = (od < 7 ? od + 1 : 7) >> 1;
+        const int pd0 = c0 > 0 ? c0 - 1 : 0, pd1 = c1 < 3 ? c1 + 1 : 3;
         float acc[LT], row[LT];
         for (int l = 0; l < LT; ++l) acc[l] = 0.0f, row[l] = 0.0f;
         for (int p = pd0 * 16; p < (pd1 + 1) * 16; ++p) {

@@ -316,7 +316,7 @@ def test_config3_four_million_leaf_file_streamed_decode(codec, oracle, tmp_path)
 
 def test_workspace_is_compact_for_inference_and_full_for_debug(pack, oracle):
     """<= 8 GB of workspace at the default 65 536-leaf chunk (three shared activation regions); debug mode
-    switches to the full layout (every intermediate at its own address) and back-to-back encode / decode on the shared regions
+    switches to the full layout (every intermediate at its own address, sized for the call that needs it) and back-to-back encode / decode on the shared regions
     stay bit-exact."""
     c = HipCodec(pack)
     c.reserve(65536)
@@ -331,8 +331,14 @@ def test_workspace_is_compact_for_inference_and_full_for_debug(pack, oracle):
         c.debug_fetch("e_a1", 32, 16, 512)
     c.debug_enable(True)
     assert np.array_equal(c.encode(leaves), idx)
-    assert c.workspace_bytes() > 1.8 * compact
+    # the switch to the full layout (every intermediate at its own address, 2.4x the bytes per leaf) is sized for what THIS call
+    # needs — 94 tiles here — not for the 65 536 leaves the handle was reserved for (that would be 16 GB for a 3000-leaf debug pass)
+    per_leaf_compact, per_leaf_full = compact / 65536, c.workspace_bytes() / (94 * 32)
+    assert c.workspace_bytes() < 0.2 * compact and per_leaf_full > 1.8 * per_leaf_compact
     assert c.debug_fetch("e_a1", 32, 16, 512).shape == (32, 16, 512)
+    c.debug_enable(False)
+    big = np.tile(leaves, (22, 1))[:65536]
+    assert np.array_equal(c.encode(big)[:3000], idx)          # grows again (a full layout also serves inference)
     c.close()
 
 

@@ -548,6 +548,12 @@ __global__ __launch_bounds__(256, 2) void conv8_c16_k(ConvArgs A, const int4* __
 //            rows of the weight fragments output VOXELS; epilogue = per-voxel bias, sigmoid, store into
 //            the caller's leaf-major [n][512] buffer (VQVAECodec.cpp:182-192).
 // ------------------------------------------------------------------------------------------
+// Folded decoder tail: does output depth plane od (0..7 at 8^3) depend on input depth plane pd (0..3 at 4^3)?  final conv taps reach
+// z = od-1 .. od+1 (inside 0..7), z lies in coarse cell z/2, the up conv's taps reach cell-1 .. cell+1 (inside 0..3).
+__device__ __forceinline__ int vq_tail_pd_lo(int od) { const int c = (od > 0 ? od - 1 : 0) >> 1; return c > 0 ? c - 1 : 0; }
+__device__ __forceinline__ int vq_tail_pd_hi(int od) { const int c = (od < 7 ? od + 1 : 7) >> 1; return c < 3 ? c + 1 : 3; }
+__device__ __forceinline__ bool vq_tail_plane_needs(int od, int pd) { return pd >= vq_tail_pd_lo(od) && pd <= vq_tail_pd_hi(od); }
+
 template <int CIN, int COUT, int NPI, int NPO, int NW, bool STREAM, int KWG, int INMODE, int GIN, bool RESID, int GOUT,
           bool CSUM, int OUTMODE>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const int4* __restrict__ steps)
@@ -645,6 +651,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];   // consumed one step later
             __syncthreads();   // every wave's pieces of W(s) are in LDS; every wave done reading W(s-1)
             const f32x4* wl = lds + (si & 1) * WSTEP + lane;
+            // OUTMODE 2 (folded tail): cout tiles 0,1 are the voxels of depth od = 2 po, tiles 2,3 those of od = 2 po + 1, and a voxel plane
+            // only depends on the input planes pd in [pd_lo(od), pd_hi(od)] (two levels of 3-tap receptive fields: od +-1 -> coarse cell
+            // -> +-1): 64 of the 224 steps feed one of the two planes only; the other plane's composite weights are structurally zero
+            // there and its MFMAs are skipped (a seventh of the kernel's matrix work).
+            // input plane pd = e.x / 16 against the two output planes of slab po (wave-uniform): which tile pairs this step feeds
+            bool act_lo = true, act_hi = true;
+            if (OUTMODE == 2 && NMT == 4) {
+                const int pd = e.x >> 4;
+                act_lo = vq_tail_plane_needs(2 * po, pd), act_hi = vq_tail_plane_needs(2 * po + 1, pd);
+            }
             f32x4 a_nx = wl[0];
 #pragma unroll
             for (int g = 0; g < NGR; ++g) {
@@ -670,6 +686,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 for (int mt = 0; mt < NMT; ++mt) {
                     const f32x4 a = a_nx;
                     if (g * NMT + mt + 1 < NGR * NMT) a_nx = wl[(g * NMT + mt + 1) * 64];   // LDS A fragment one group ahead of its MFMAs
+                    if (OUTMODE == 2 && NMT == 4 && !(mt < NMT / 2 ? act_lo : act_hi)) continue;   // (wave-uniform) structurally zero weights
                     acc[mt] = mfma32(a.x, b.x, acc[mt]);
                     acc[mt] = mfma32(a.y, b.y, acc[mt]);
                     acc[mt] = mfma32(a.z, b.z, acc[mt]);
@@ -753,15 +770,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, q = lane >> 5;
     const int tile = blockIdx.x, d = blockIdx.y;
-    const int p0 = (d > 2 ? d - 2 : 0) * 16, p1 = ((d + 2 < 3 ? d + 2 : 3) + 1) * 16;   // an even number of positions (48 or 64)
-    const int sbase = d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176;                      // first step of slab d in tail.w
+    // the slab's fragments cover input planes [d-2, d+2] (first one: ps0); this wave's 32 voxels lie in depth plane od = 2d + mb/2 and
+    // depend on planes pd_lo(od) .. pd_hi(od) only (the rest of the slab's composite weights are structurally zero for them)
+    const int od = 2 * d + (mb >> 1);
+    const int ps0 = (d > 2 ? d - 2 : 0) * 16;
+    const int p0 = vq_tail_pd_lo(od) * 16, p1 = (vq_tail_pd_hi(od) + 1) * 16;             // an even number of positions (32, 48 or 64)
+    const int sbase = (d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176) - ps0;              // step of position 0 in tail.w for slab d
     float ta[NU][4];   // attention gates of this lane's channels 8u + 4q + i (precomputed once per tile by csum_seq_k)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ta[u][i] = A.se_gate[((size_t)tile * CIN + 8 * u + 4 * q + i) * 32 + j];
     const f32x4* in4 = (const f32x4*)A.in + (size_t)tile * NPI * (CIN / 4) * 32 + q * 32 + j;       // + p*(CIN/4)*32 + u*64
-    const f32x4* w4 = (const f32x4*)A.wfrag + ((size_t)(sbase - p0) * NU * NMT + mb) * 64 + lane;   // + (p*NU*NMT + u*NMT)*64
+    const f32x4* w4 = (const f32x4*)A.wfrag + ((ptrdiff_t)sbase * NU * NMT + mb) * 64 + lane;   // + (p*NU*NMT + u*NMT)*64
     f32x4 w[2][NU], b[2][NU];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -843,9 +864,12 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
     const int tile = blockIdx.x, d = blockIdx.y, unit = blockIdx.z * 4 + wave;   // 16 units: 8 voxel blocks x 2 leaf halves
     const int mb = unit >> 1, half = unit & 1;
     const int n = lane & 15, q4 = lane >> 4, jj = 16 * half + n;
-    const int p0 = (d > 2 ? d - 2 : 0) * 16, p1 = ((d + 2 < 3 ? d + 2 : 3) + 1) * 16;   // 48 or 64 positions: multiples of DEPTH
-    const int sbase = d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176;                      // first step of slab d in tail.w16
-    static_assert(48 % DEPTH == 0 && 64 % DEPTH == 0, "whole rings");
+    // this wave's 16 voxels lie in depth plane od = 2d + mb/4 and depend on input planes pd_lo(od) .. pd_hi(od) only (see tail_small_k)
+    const int od = 2 * d + (mb >> 2);
+    const int ps0 = (d > 2 ? d - 2 : 0) * 16;
+    const int p0 = vq_tail_pd_lo(od) * 16, p1 = (vq_tail_pd_hi(od) + 1) * 16;             // 32, 48 or 64 positions: multiples of DEPTH
+    const int sbase = (d == 0 ? 0 : d == 1 ? 48 : d == 2 ? 112 : 176) - ps0;              // step of position 0 in tail.w16 for slab d
+    static_assert(32 % DEPTH == 0 && 48 % DEPTH == 0 && 64 % DEPTH == 0, "whole rings");
     float ta[8][2];   // attention gates of this lane's channels (computed once per tile by csum_combine_k)
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -858,7 +882,7 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
     f32x4 w[DEPTH][4], b[DEPTH][8];
     auto request = [&](int h, int p) {
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) w[h][uu] = buf_ld16(wb, lane_w, (unsigned)(((sbase - p0 + p) * 8 + mb) * 4 + uu) * 1024u);
+        for (int uu = 0; uu < 4; ++uu) w[h][uu] = buf_ld16(wb, lane_w, (unsigned)(((sbase + p) * 8 + mb) * 4 + uu) * 1024u);
 #pragma unroll
         for (int u = 0; u < 8; ++u) b[h][u] = buf_ld16(inb, lane_x, (unsigned)(p * (CIN / 4) + 2 * u) * 512u);
     };
