@@ -138,8 +138,10 @@ const std::map<std::string, KernelInfo>& kernel_info()
         {"dec_res64_conv1", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         {"dec_res64_conv2", {2.0 * 7077888, 2.0 * 7077888 * 0.578704}},
         // folded up_conv+pixshuf+final: nominal = the reference ops' dense count; "effective" = the MACs the
-        // folded map really needs (884 736/leaf); the kernel issues 224 steps x 128 x 64 = 1 835 008 MAC/leaf
-        {"dec_tail", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1835008}},
+        // folded map really needs (884 736/leaf); the kernel issues (160 steps x 4 + 64 steps x 2 cout tiles) x 32 voxels x 64
+        // channels = 1 572 864 MAC/leaf (round 3: the MFMAs of a voxel plane against input planes it cannot depend on are skipped;
+        // 224 steps x 128 x 64 = 1 835 008 before)
+        {"dec_tail", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1572864}},
     };
     return m;
 }
@@ -764,7 +766,7 @@ int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
         c->ws = nullptr;
         c->ws_tiles = 0;
         c->ws_bytes = 0;
-        for (auto& kv : c->act) kv.second = nullptr;
+        for (const ActSpec& a : kActs) c->act[a.name] = nullptr;   // (only this workspace's names: the training step registers its own buffers in the same table)
     }
     size_t total = workspace_bytes(new_tiles, full);
     hipError_t e = hipMalloc(&c->ws, total);
