@@ -44,11 +44,13 @@
  *     sigmoid(x) = 1/(1+vq_expf(-x)) with the polynomial vq_expf below.
  *   * VQ (default, what the GPU runs): the 1x1x1 projection z = P x' + b (VQVAE_v2.py:243) is folded into
  *     the nearest-code search (:364-367).  ||z||^2 is the same for every code, and
- *     z.e_k = x'.(P^T e_k) + b.e_k, so  argmin_k dist_k = argmin_k [ c_k - 2 * (x' . Ep_k) ]  with
+ *     z.e_k = x'.(P^T e_k) + b.e_k, so  argmin_k dist_k = argmax_k [ h_k + x' . Ep_k ]  with
  *       Ep_k[c] = (float) sum_j fma(e_k[j], P[j][c], .)            (fp64 chain, j ascending)
- *       c_k     = (float) ( sum_j e_k[j]^2 - 2 * sum_j b[j] e_k[j] )  (fp64 chains, j ascending)
- *       x'.Ep_k = fmaf chain over the 32 gated channels in "P8" order from 0
- *     score = c_k - 2*dot; argmin = first minimum (torch.argmin).  Exact algebra; it differs from
+ *       h_k     = (float) ( sum_j b[j] e_k[j] - (sum_j e_k[j]^2) / 2 )  (fp64 chains, j ascending)
+ *       s_k     = fmaf chain over the 32 gated channels in "P8" order STARTING AT h_k  (= -dist_k/2 + const;
+ *                 round 3 — the start value is the MFMA's C operand, so a candidate costs the GPU no score
+ *                 operation; rounds 1-2: chain from 0, then score = c_k - 2*dot with c_k = -2 h_k)
+ *     nearest code = FIRST maximum of s_k (torch.argmin's first minimum).  Exact algebra; it differs from
  *     the reference's fp32 expression only in rounding, i.e. only on near-ties.
  *   * VQ (faithful cross-check, vqo_encode_ex(faithful=1)): z = conv1x1, dist = (zz + ee[k]) - 2*dot[k]
  *     exactly as VQVAE_v2.py:364-366, dot in "P8" order over the 128 latent channels.
@@ -545,7 +547,7 @@ typedef struct {
 /* projection folded into the codebook (see the VQ contract in the header) */
 typedef struct {
     float ep[256 * 32];
-    float ck[256];
+    float hk[256];
 } vqfold_t;
 
 static void vqfold_build(vqfold_t* f, const float* E /*[256][128]*/, const float* P /*[128][32]*/, const float* b /*[128]*/)
@@ -561,7 +563,7 @@ static void vqfold_build(vqfold_t* f, const float* E /*[256][128]*/, const float
             cc = fma((double)E[k * 128 + j], (double)E[k * 128 + j], cc);
             bb = fma((double)b[j], (double)E[k * 128 + j], bb);
         }
-        f->ck[k] = (float)(cc - 2.0 * bb);
+        f->hk[k] = (float)(bb - 0.5 * cc);   /* h_k = -c_k / 2 = b.e_k - ||e_k||^2 / 2 */
     }
 }
 
@@ -644,10 +646,10 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
     for (int p = 0; p < 64; ++p) {
         float best[LT];
         int bi[LT];
-        for (int l = 0; l < LT; ++l) { best[l] = INFINITY; bi[l] = 0; }
+        for (int l = 0; l < LT; ++l) { best[l] = -INFINITY; bi[l] = 0; }
         for (int k0 = 0; k0 < 256; k0 += 4) {
             float dot[4][LT];
-            for (int b = 0; b < 4; ++b) for (int l = 0; l < LT; ++l) dot[b][l] = 0.0f;
+            for (int b = 0; b < 4; ++b) for (int l = 0; l < LT; ++l) dot[b][l] = fold->hk[k0 + b];   /* the chain starts at h_k */
             for (int cc = 0; cc < 32; ++cc) {
                 const int c = p8_32[cc];
                 const float* v = x12 + ((size_t)c * 64 + p) * LT;
@@ -657,10 +659,8 @@ static void encode_tile(const float* const* W, const float* leaves, int64_t leaf
                 }
             }
             for (int b = 0; b < 4; ++b)
-                for (int l = 0; l < LT; ++l) {
-                    const float sc = fold->ck[k0 + b] - 2.0f * dot[b][l];
-                    if (sc < best[l]) { best[l] = sc; bi[l] = k0 + b; }
-                }
+                for (int l = 0; l < LT; ++l)
+                    if (dot[b][l] > best[l]) { best[l] = dot[b][l]; bi[l] = k0 + b; }   /* first maximum */
         }
         for (int l = 0; l < nl; ++l) idx[(size_t)(leaf0 + l) * 64 + p] = (uint8_t)bi[l];
     }

@@ -1391,10 +1391,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
 // Encoder tail: ChannelAttention(32) (VQVAE_v2.py:242) -> Conv3d(32->128,k1) (:243) -> nearest
 // codebook row (:358-367), with the projection FOLDED into the search:  ||z||^2 is the same for
 // every code and z.e_k = x'.(P^T e_k) + b.e_k, so
-//     argmin_k dist_k = argmin_k [ c_k - 2 * x'.Ep_k ],   Ep = E P  (256 x 32),  c_k = ||e_k||^2 - 2 b.e_k
-// (Ep, c built in fp64 at vqhip_create).  Per position: 8 code tiles x 16 MFMAs on the 32 gated
+//     argmin_k dist_k = argmax_k [ h_k + x'.Ep_k ],   Ep = E P  (256 x 32),  h_k = b.e_k - ||e_k||^2 / 2
+// (Ep, h built in fp64 at vqhip_create; the fmaf chain of candidate k starts at h_k: it is the MFMA's C operand).  Per position: 8 code tiles x 16 MFMAs on the 32 gated
 // channels instead of 64 (projection) + 512 (128-d distances); the 128-channel latent is never
-// formed.  Ep fragments (32 KB) and c (1 KB) live in LDS.  First-minimum argmin like torch.argmin.
+// formed.  Ep fragments (32 KB) and h (1 KB) live in LDS.  First maximum = torch.argmin's first minimum.
 // ------------------------------------------------------------------------------------------
 struct VqArgs {
     const float* in;        // x11 L4 [tile][64][8][32][4]
@@ -1403,7 +1403,7 @@ struct VqArgs {
     const float* se_fc2;    // [32][8]
     const float* se_gate;   // optional: gates precomputed per tile (position-split launches), [tile][32][32]
     const float* epfrag;    // A fragments of Ep: [u=4][ct=8][64][4]
-    const float* ck_frag;   // D-fragment order [(ct*2+q)*16 + r]
+    const float* ck_frag;   // h_k in D-fragment order [(ct*2+q)*16 + r]
     uint8_t* idx;           // [n_leaves][64]
     int64_t n_leaves;
     int n_tiles;
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
         const int pn = p < 63 ? p + 1 : 63;
 #pragma unroll
         for (int u = 0; u < 4; ++u) bn[u] = in4[((size_t)pn * 8 + 2 * u) * 32];
-        float best = __builtin_inff();
+        float best = -__builtin_inff();
         int bk = 0;
         const f32x4* el = ldsE + lane;
 #pragma unroll 2
@@ -1468,9 +1468,11 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             f32x4 ck[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) ck[g] = ldsC[(ct * 2 + q) * 4 + g];
+            // the chain of candidate k starts at h_k = -c_k / 2 (the MFMA's C operand) and ends as  h_k + x'.Ep_k = -score_k / 2:
+            // nearest code = FIRST MAXIMUM, no per-candidate score op (round 3; c_k - 2 dot after a chain from zero before)
             f32x16 d;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+            for (int g = 0; g < 4; ++g) d[4 * g + 0] = ck[g].x, d[4 * g + 1] = ck[g].y, d[4 * g + 2] = ck[g].z, d[4 * g + 3] = ck[g].w;
             d = mfma32(a0.x, b[0].x, d);
             d = mfma32(a0.y, b[0].y, d);
             d = mfma32(a0.z, b[0].z, d);
@@ -1491,13 +1493,11 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float c = i == 0 ? ck[g].x : (i == 1 ? ck[g].y : (i == 2 ? ck[g].z : ck[g].w));
-                    // c - 2*dot in one rounding either way (2*dot is exact): one fused op instead of an add and a subtract; the lane's
-                    // own code offset 4q is added after the scan so that the candidate index is wave-uniform (an immediate operand
-                    // of the select, not a per-candidate vector add) — 4 vector ops per candidate instead of 6
-                    const float score = __builtin_fmaf(-2.0f, d[4 * g + i], c);
+                    // the lane's own code offset 4q is added after the scan so that the candidate index is wave-uniform (an immediate
+                    // operand of the select, not a per-candidate vector add) — 3 vector ops per candidate (compare, two selects)
+                    const float score = d[4 * g + i];
                     const int k = 32 * ct + i + 8 * g;
-                    if (score < best) {
+                    if (score > best) {
                         best = score;
                         bk = k;
                     }
@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
         bk += 4 * q;
         const float ob = __shfl_xor(best, 32, 64);
         const int ok = __shfl_xor(bk, 32, 64);
-        if (ob < best || (ob == best && ok < bk)) bk = ok;
+        if (ob > best || (ob == best && ok < bk)) bk = ok;
         // four consecutive positions of a leaf leave as one 32-bit store (a byte store per position touches 32 cache lines for 32 bytes)
         if (packed) {
             pk |= (unsigned)bk << (8 * (p & 3));

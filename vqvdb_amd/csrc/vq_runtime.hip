@@ -502,7 +502,7 @@ int upload(vqhip_codec* c, const char* name, const PackTensor* t)
 }
 
 // Projection folded into the codebook (contract: oracle vqfold_build): Ep = E P in fp64 (j ascending),
-// c_k = sum e^2 - 2 sum b e, both rounded to fp32 once.  E = codebook [256][128] on the host.
+// h_k = sum b e - (sum e^2) / 2, both rounded to fp32 once.  E = codebook [256][128] on the host.
 int build_vq_fold(vqhip_codec* c, const float* E)
 {
     std::vector<float> ep(256 * 32), ck(256);
@@ -519,7 +519,7 @@ int build_vq_fold(vqhip_codec* c, const float* E)
             cc = __builtin_fma((double)E[k * 128 + jx], (double)E[k * 128 + jx], cc);
             bb = __builtin_fma((double)pb[jx], (double)E[k * 128 + jx], bb);
         }
-        ck[k] = (float)(cc - 2.0 * bb);
+        ck[k] = (float)(bb - 0.5 * cc);   // h_k = -c_k / 2: where the score chain of code k starts (oracle vqfold_build)
     }
     int rc;
     if ((rc = upload(c, "vq.ep", frag32(ep.data(), 256, 32, 1)))) return rc;
