@@ -1489,20 +1489,23 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             d = mfma32(a3.y, b[3].y, d);
             d = mfma32(a3.z, b[3].z, d);
             d = mfma32(a3.w, b[3].w, d);
+            // Three vector ops per candidate (compare, two selects).  The select of the index takes the candidate's number INSIDE the tile
+            // (i + 8g <= 27: an inline constant; 32 ct + i + 8g is a literal the compiler first moves into a register, one more op per
+            // candidate); 63 = "no candidate of this tile beat the running best", the tile offset joins once per tile; the lane's own
+            // code offset 4q once per position.
+            int loc = 63;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    // the lane's own code offset 4q is added after the scan so that the candidate index is wave-uniform (an immediate
-                    // operand of the select, not a per-candidate vector add) — 3 vector ops per candidate (compare, two selects)
                     const float score = d[4 * g + i];
-                    const int k = 32 * ct + i + 8 * g;
                     if (score > best) {
                         best = score;
-                        bk = k;
+                        loc = i + 8 * g;
                     }
                 }
             }
+            if (loc != 63) bk = 32 * ct + loc;
         }
         bk += 4 * q;
         const float ob = __shfl_xor(best, 32, 64);
