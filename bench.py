@@ -77,12 +77,54 @@ def profile_pass(codec, fn, steps, device):
     return out
 
 
+# FLOPs per leaf the full training step issues on the matrix pipe (2 x MACs; zero-padding taps skipped — tap fractions 0.7703 at 8^3 k3,
+# 0.5787 at 4^3 k3, 0.6699 for k4 s2 — the decoder tail as ONE folded operator, forward and backward):
+#   forward : first conv 170 k + 16->16 convs 2 x 2.726 M + down 1.405 M + 32->32 convs 2 x 1.024 M + projection 0.262 M + distances to
+#             the 256 codes on the materialised latent 2.097 M + decoder stem as a real conv 8.192 M + 64->64 convs 2 x 4.096 M + folded
+#             tail 1.573 M                                                                                   = 29.39 M MAC
+#   dgrad   : every layer but the first conv (transposed convs on the forward kernels: the same MACs), folded tail through the
+#             transposed operator 1.835 M                                                                    = 27.39 M MAC
+#   wgrad   : every conv layer (dW = sum over leaves and positions of dY X^T: the forward's MACs), folded tail 1.835 M = 27.56 M MAC
+TRAIN_ISSUED_FLOP = {"forward": 2 * 29.39e6, "dgrad": 2 * 27.39e6, "wgrad": 2 * 27.56e6}
+
+
+def train_step_classes(codec, step_fn, leaves, device, steps=3):
+    """Per kernel class of the full training step (HIP events of the library's profiler over `steps` steps): time, issued TFLOP/s and the
+    fraction of the fp32-MFMA peak.  Classes by launch name: *_wgrad* weight gradients, *_dgrad* data gradients, the forward's
+    MFMA kernels, everything else (statistics, elementwise GroupNorm / attention forward and backward, loss, optimizer, table rebuilds)."""
+    fwd = ("enc_conv_first", "enc_res16_conv", "enc_down", "enc_res32_conv", "train_latent_assign", "ft_stem", "ft_res64_conv", "ft_tail", "ft_up_conv", "ft_final")
+    torch.cuda.synchronize(device)
+    codec.profile_enable(True)
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize(device)
+    stats = codec.profile_read()
+    codec.profile_enable(False)
+    ms = {"forward": 0.0, "dgrad": 0.0, "wgrad": 0.0, "other": 0.0}
+    for st in stats:
+        n = st["name"]
+        cls = "wgrad" if "_wgrad" in n else "dgrad" if "_dgrad" in n else "forward" if n.startswith(fwd) and n != "ft_tail_fold" else "other"
+        ms[cls] += st["total_ms"] / steps
+    out = {"kernel_time_ms_per_step": round(sum(ms.values()), 4)}
+    for cls, t in ms.items():
+        e = {"ms": round(t, 4)}
+        if cls in TRAIN_ISSUED_FLOP and t > 0:
+            tf = TRAIN_ISSUED_FLOP[cls] * leaves / (t * 1e-3) / 1e12
+            e.update(tflops_issued=round(tf, 2), frac=round(tf / PEAK_TF, 4))
+        out[cls] = e
+    return out
+
+
 def hbm_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/hbm_traffic_per_launch.json,
     tools/make_traffic_json.py): FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE.  None if not profiled."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")))[kernel]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from make_traffic_json import kernel_build_id
+        now = kernel_build_id()
         return {"bytes": t["fetch_bytes"] + t["write_bytes"], "fetch_bytes": t["fetch_bytes"], "write_bytes": t["write_bytes"],
+                "collected_on_build": t.get("build"), "this_build": now, "stale": t.get("build") != now,
                 "source": t["source"], "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at 65536 leaves per launch; " + t["correction"]}
     except (OSError, KeyError, ValueError):
         return None
@@ -343,7 +385,11 @@ def main():
             full = {"note": "one optimizer step = training-mode forward (unfolded decoder) + backward of every layer + all-reduce + AdamW + EMA "
                             "codebook update + rebuild of the weight-derived tables, fp32; not the headline value",
                     "collective": coll("995905 + 33284"),
-                    "flop_per_leaf_nominal": 3 * (ENC_FLOP + DEC_FLOP)}
+                    "flop_per_leaf_nominal": 3 * (ENC_FLOP + DEC_FLOP), "flop_per_leaf_issued": TRAIN_ISSUED_FLOP,
+                    "frac_note": "whole_step_frac and by_class[*].frac count the FLOPs the step ISSUES on the matrix pipe (padding taps skipped, folded tail at its "
+                                 "folded cost; forward + data gradients + weight gradients, TRAIN_ISSUED_FLOP in bench.py) over the measured time / 157.3 TFLOP/s: "
+                                 "true utilisations, <= 1.  ratio_nominal_dense_* = 3 x the dense forward count of the reference ops over the same time: what the "
+                                 "algebraic eliminations buy, not a utilisation (it exceeds 1 at 8192 leaves per rank)"}
             ksteps = max(2, min(args.steps, 6))
             for per_rank_b in (2048, 8192):
                 x = leaves[0][:per_rank_b]
@@ -352,9 +398,13 @@ def main():
                 t_ft, _ = timed(lambda s: ftr.step(x, want_metrics=False), ksteps, dist, device)
                 last = ftr.step(x)
                 lps = world * ksteps * per_rank_b / t_ft
-                full[f"per_rank_batch_{per_rank_b}"] = {"leaves_per_s": round(lps, 1), "ms_per_step": round(t_ft / ksteps * 1e3, 4), "steps": ksteps,
-                                                         "loss": round(last["loss"], 6), "perplexity": round(last["perplexity"], 3),
-                                                         "ratio_nominal_dense_to_fp32_mfma_peak": round(lps / world * 3 * (ENC_FLOP + DEC_FLOP) / (PEAK_TF * 1e12), 4)}
+                entry = {"leaves_per_s": round(lps, 1), "ms_per_step": round(t_ft / ksteps * 1e3, 4), "steps": ksteps,
+                         "loss": round(last["loss"], 6), "perplexity": round(last["perplexity"], 3),
+                         "whole_step_frac": round(lps / world * sum(TRAIN_ISSUED_FLOP.values()) / (PEAK_TF * 1e12), 4),
+                         "ratio_nominal_dense_to_fp32_mfma_peak": round(lps / world * 3 * (ENC_FLOP + DEC_FLOP) / (PEAK_TF * 1e12), 4)}
+                if rank == 0:
+                    entry["by_class"] = train_step_classes(fcodec, lambda: ftr.step(x, want_metrics=False), per_rank_b, device)
+                full[f"per_rank_batch_{per_rank_b}"] = entry
             fcodec.close()
         except Exception as e:  # noqa: BLE001 — never take the headline measurement down
             full = {"error": f"{type(e).__name__}: {e}"}

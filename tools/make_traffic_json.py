@@ -3,10 +3,24 @@
 bench.py reports roofline.traffic from this file (it cannot collect PMC counters itself).
 FETCH_SIZE is doubled per the gfx950 calibration of MI355X_MICROARCH.md §HBM (verified here: the
 elementwise kernel's corrected 2050 MB vs 2048 MB algorithmic); WRITE_SIZE is used as reported."""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+
+def kernel_build_id():
+    """sha256 (12 hex) over the kernel sources of vqvdb_amd/csrc, in name order: what the counters were collected on.  bench.py computes
+    the same id from the tree it runs and flags roofline.traffic as stale when they differ."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vqvdb_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:12]
 
 LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the library's profiler)
     (r"conv_first_k<0>", "enc_conv_first_stats"), (r"conv_first_k<1>", "enc_conv_first_gn"),
@@ -42,7 +56,8 @@ def read(path, counter):
 def main():
     fetch_db, write_db, source, out = sys.argv[1:5]
     f, w = read(fetch_db, "FETCH_SIZE"), read(write_db, "WRITE_SIZE")
-    res = {k: {"fetch_bytes": round(2.0 * f[k]), "write_bytes": round(w.get(k, 0.0)), "leaves_per_launch": 65536, "source": source,
+    build = kernel_build_id()
+    res = {k: {"fetch_bytes": round(2.0 * f[k]), "write_bytes": round(w.get(k, 0.0)), "leaves_per_launch": 65536, "source": source, "build": build,
                "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE as reported"} for k in f}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(out, len(res), "kernels")

@@ -13,13 +13,17 @@ SHORT="--steps 4 --warmup 1 --no-cpu-baseline --no-train --no-host-path"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_sq.err
+# L2 (TCC) requests / hits / misses per kernel: which part of a kernel's operand traffic the L2 absorbs (weights, re-read activations)
+# and which part goes on to the fabric (Infinity Cache / HBM) — VERDICT r2 item 6
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -d $OUT/pmc_tcc -o r02 -- python $R/bench.py $SHORT > /dev/null 2> $OUT/pmc_tcc.err
 find $OUT -name "*.db" | xargs ls -la
 cat $OUT/bench.json | head -c 600
 # summaries (small text / json files for profiles/); the databases themselves stay on the box
-TAG=${PROFILE_TAG:-r02_v1}
+TAG=${PROFILE_TAG:-r03_v1}
 SUM=$R/gpurun_out/prof_sum; mkdir -p $SUM
 python $R/tools/rocpd_summary.py --kt $OUT/kt/r02_results.db --fetch $OUT/pmc_fetch/r02_results.db --write $OUT/pmc_write/r02_results.db > $SUM/${TAG}_bench_rocprofv3_summary.txt
 python $R/tools/pmc_sq_summary.py $OUT/pmc_sq/r02_results.db > $SUM/${TAG}_pmc_mfma_util_clock.txt
+python $R/tools/pmc_tcc_summary.py $OUT/pmc_tcc/r02_results.db $OUT/pmc_fetch/r02_results.db > $SUM/${TAG}_pmc_l2_hit_miss.txt 2> $SUM/${TAG}_pmc_l2.err || tail -3 $OUT/pmc_tcc.err
 python $R/tools/make_traffic_json.py $OUT/pmc_fetch/r02_results.db $OUT/pmc_write/r02_results.db "profiles/${TAG}_bench_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_round.sh)" $SUM/hbm_traffic_per_launch.json
 cp $OUT/bench.json $SUM/${TAG}_bench.json; cp $OUT/bench_under_rocprof.json $SUM/${TAG}_bench_under_rocprof.json
 find $OUT -name "*.db" | xargs rm -f
