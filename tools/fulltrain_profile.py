@@ -28,7 +28,7 @@ for n in [int(a) for a in sys.argv[1:]] or [2048]:
     for st in codec.profile_read():
         ms = st["total_ms"] / st["launches"]
         tot += ms
-        if ms > 0.02:
+        if ms > 0.004:
             print(f"  {st['name']:26s} {ms:8.4f} ms")
     print(f"  {'sum of kernels':26s} {tot:8.4f} ms")
     codec.close()

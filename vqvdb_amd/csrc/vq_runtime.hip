@@ -156,7 +156,7 @@ struct vqhip_codec {
     int64_t chunk = 65536;
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: one kernel; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
-    bool stem_taps = false;  // VQHIP_STEM=taps: the table streamed through LDS tap by tap (stem_taps_k, vq_stem_taps.h) instead of gathered through the L1 — measured slower (0.91 vs 0.82 ms), kept selectable
+    bool stem_taps = true;   // ... the (tap, code) table streamed through an LDS ring tap by tap (stem_taps_k, vq_stem_taps.h: 0.81 -> 0.57 ms); VQHIP_STEM=gather selects stem_fused_k (gather through the L1)
     int tail16_tiles = 48;   // small-batch folded tail on the 16x16x4 MFMA up to this many tiles (VQHIP_TAIL16_TILES; measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us)
     bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
     int vq_split = 2;        // position ranges per tile in the VQ search of full chunks (VQHIP_VQ_SPLIT)
@@ -1256,7 +1256,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
         F.steps = (const int4*)w["steps.k3s1_4"], F.grp_start = reinterpret_cast<const int*>(w["steps.k3s1_4.grp"]), F.n_steps = c->nsteps["steps.k3s1_4"];
         F.n_leaves = n, F.n_tiles = nt;
-        if (c->stem_taps) L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_taps_k, dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
+        if (c->stem_taps) L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_taps_k, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
         else L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_fused_k, dim3(8 * nt), dim3(512), 0, s, F); });
     } else {
         L.run("dec_stem", [&] {
@@ -1627,7 +1627,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "taps") == 0;
+    if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "gather") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->err = "hipStreamCreate failed";
