@@ -402,8 +402,10 @@ def main():
                          "loss": round(last["loss"], 6), "perplexity": round(last["perplexity"], 3),
                          "whole_step_frac": round(lps / world * sum(TRAIN_ISSUED_FLOP.values()) / (PEAK_TF * 1e12), 4),
                          "ratio_nominal_dense_to_fp32_mfma_peak": round(lps / world * 3 * (ENC_FLOP + DEC_FLOP) / (PEAK_TF * 1e12), 4)}
+                # (every rank runs the profiled steps: a step contains the gradient all-reduce)
+                by_class = train_step_classes(fcodec, lambda: ftr.step(x, want_metrics=False), per_rank_b, device)
                 if rank == 0:
-                    entry["by_class"] = train_step_classes(fcodec, lambda: ftr.step(x, want_metrics=False), per_rank_b, device)
+                    entry["by_class"] = by_class
                 full[f"per_rank_batch_{per_rank_b}"] = entry
             fcodec.close()
         except Exception as e:  # noqa: BLE001 — never take the headline measurement down

@@ -577,3 +577,19 @@ def test_decompress_the_file_the_reference_writer_wrote(codec):
         for (name, tr, org, leaves), g in zip(grids, want):
             assert name == g.name and np.array_equal(tr, g.transform) and np.array_equal(org, g.origins)
             assert np.array_equal(_bits(leaves), _bits(codec.decode(g.indices)))
+
+
+def test_orchestrator_loop_bench_harness(pack, tmp_path):
+    """`leaf_harness loopbench` (bench.py -> orchestrator_loop): the reference orchestrator's serial compress / decompress loops through
+    IVQVAECodec::create + the adapter, per-phase timing lines parsed by vqvdb_amd/hostbench.py; the decompress leg checks the leaf count."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from vqvdb_amd import hostbench
+    harness = os.path.join(ROOT, "vqvdb_amd", "host", "leaf_harness")
+    pk = tmp_path / "w.vqw"
+    pk.write_bytes(pack)
+    r = subprocess.run([harness, "loopbench", str(pk), "20000", str(tmp_path / "loop.vqvdb"), "64,1000,8192"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    legs = [(m.group(1), int(m.group(2)), int(m.group(3))) for m in hostbench.LOOP_RE.finditer(r.stdout)]
+    assert legs == [(d, b, 20000) for b in (64, 1000, 8192) for d in ("compress", "decompress")], r.stdout

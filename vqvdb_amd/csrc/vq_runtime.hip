@@ -1183,18 +1183,28 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
     auto combine64 = [&](const char* name, float* mean, float* rstd) {
         L.run(name, [&] { hipLaunchKernelGGL(gn_combine_k<true>, dim3(nt), dim3(512), 0, s, ps, pq, mean, rstd, 8, 1.0 / 512.0); });
     };
-    L.run("dec_stem_s", [&] {
-        hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt, split_factor(2 * nt, 2, 16, 2048)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
-                           (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"), ps, pq);
-    });
-    combine64("dec_stats_ystem", a["st_a.mean"], a["st_a.rstd"]);
-    {
-        ConvArgs A{};
-        A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
-        A.in_gamma = w["dg0.w"], A.in_beta = w["dg0.b"], A.n_tiles = nt, A.part_s = ps, A.part_q = pq;
-        L.run("dec_gn_relu_d2", [&] { hipLaunchKernelGGL((gn_relu_stats_k<64, 64, 8>), dim3(g4, split_factor(g4, 2, 16, 1024)), dim3(256), 0, s, A); });
+    if (c->stem_fused && c->stem_taps && nt >= c->n_cus) {
+        // mid-size passes (a tile per CU and more): the decoder front as ONE kernel (table through the LDS ring, stem_taps_k) instead of
+        // gather + combine + normalise + combine; same d2 and statistics bit for bit
+        StemFusedArgs F{};
+        F.idx = d_idx, F.T = w["ds.lut"], F.bias = w["ds.b"], F.gamma = w["dg0.w"], F.beta = w["dg0.b"], F.d2 = a["d_d2"];
+        F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
+        F.n_leaves = n, F.n_tiles = nt;
+        L.run("dec_stem_gn_s", [&] { hipLaunchKernelGGL(stem_taps_k, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
+    } else {
+        L.run("dec_stem_s", [&] {
+            hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt, split_factor(2 * nt, 2, 16, 2048)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
+                               (const int4*)w["steps.k3s1_4"], c->nsteps["steps.k3s1_4"], n, nt, od("steps.k3s1_4"), ps, pq);
+        });
+        combine64("dec_stats_ystem", a["st_a.mean"], a["st_a.rstd"]);
+        {
+            ConvArgs A{};
+            A.in = a["d_ystem"], A.out = a["d_d2"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"];
+            A.in_gamma = w["dg0.w"], A.in_beta = w["dg0.b"], A.n_tiles = nt, A.part_s = ps, A.part_q = pq;
+            L.run("dec_gn_relu_d2", [&] { hipLaunchKernelGGL((gn_relu_stats_k<64, 64, 8>), dim3(g4, split_factor(g4, 2, 16, 1024)), dim3(256), 0, s, A); });
+        }
+        combine64("dec_stats_d2", a["st_b.mean"], a["st_b.rstd"]);
     }
-    combine64("dec_stats_d2", a["st_b.mean"], a["st_b.rstd"]);
     {
         ConvArgs A{};
         A.in = a["d_d2"], A.out = a["d_y4"], A.wfrag = w["r64c1.w"], A.bias_frag = w["r64c1.b"];
