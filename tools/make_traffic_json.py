@@ -30,7 +30,7 @@ LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the lib
     (r"conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true[,>]", "enc_res32_conv1"),
     (r"conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true[,>]", "enc_res32_conv2"),
     (r"vq_folded_k<8>", "enc_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
-    (r"gn_relu_stats_k<64", "dec_gn_relu_stats"), (r"stem_fused_k", "dec_stem_gn"),
+    (r"gn_relu_stats_k<64", "dec_gn_relu_stats"), (r"stem_fused_k", "dec_stem_gn"), (r"stem_taps_k", "dec_stem_gn"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false[,>]", "dec_res64_conv1"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false[,>]", "dec_res64_conv2"),
     (r"conv_mfma32_k<64, 128, 64, 4, 8,", "dec_tail"),
@@ -42,7 +42,8 @@ def read(path, counter):
     throughput legs; the same kernels also run at small batches and with gridDim.y > 1)."""
     db = sqlite3.connect(path)
     out, best = {}, {}
-    for name, grid, gy, avg in db.execute("select kernel_name, grid_size_x, grid_size_y, avg(value) from counters_collection where counter_name=? "
+    # max, not avg: a persistent kernel (grid = CUs) has the same grid for its 65536-leaf launches and for mid-size passes
+    for name, grid, gy, avg in db.execute("select kernel_name, grid_size_x, grid_size_y, max(value) from counters_collection where counter_name=? "
                                           "group by kernel_name, grid_size_x, grid_size_y", (counter,)):
         if gy != 1:   # position-split launches (small batches)
             continue

@@ -6,7 +6,7 @@
 // by the 16-block rule; tests/test_gpu_parity.py::test_large_path_kernel_variants_agree compares the two).
 //
 // stem_fused_k walks POSITIONS and gathers every tap's 256-byte table row of a position through the L1: 256 KB per leaf, 16.8 GB per
-// 65 536 leaves, and that gather is bound by the L1 (80 B/clk/CU; 8.7 GB of it miss to the L2, profiles/r03_v1_pmc_l2_hit_miss.txt):
+// 65 536 leaves, and that gather is bound by the L1 (80 B/clk/CU; 8.7 GB of it miss to the L2, profiles/r03_archive/r03_v1_pmc_l2_hit_miss.txt):
 // 0.81 ms, 8 % of decode without one MFMA.  Here the TAPS are the outer loop.  A persistent workgroup owns a whole 32-leaf tile and ONE
 // CHANNEL HALF at a time (GroupNorm groups of 8 channels never straddle the halves, so the two halves of a tile are independent
 // passes): the accumulators of 32 leaves x 64 positions x 32 channels live in registers (128 VGPRs per lane), a slice of the table is
