@@ -80,12 +80,13 @@ def profile_pass(codec, fn, steps, device):
 # FLOPs per leaf the full training step issues on the matrix pipe (2 x MACs; zero-padding taps skipped — tap fractions 0.7703 at 8^3 k3,
 # 0.5787 at 4^3 k3, 0.6699 for k4 s2 — the decoder tail as ONE folded operator, forward and backward):
 #   forward : first conv 170 k + 16->16 convs 2 x 2.726 M + down 1.405 M + 32->32 convs 2 x 1.024 M + projection 0.262 M + distances to
-#             the 256 codes on the materialised latent 2.097 M + decoder stem as a real conv 8.192 M + 64->64 convs 2 x 4.096 M + folded
-#             tail 1.573 M                                                                                   = 29.39 M MAC
+#             the 256 codes on the materialised latent 2.097 M + 64->64 convs 2 x 4.096 M + folded tail 1.573 M   = 21.20 M MAC
+#             (the decoder stem runs through the (tap, code) table rebuilt every step: 56.6 M MAC per STEP, not per leaf — round 3;
+#             as a real conv it was 8.192 M MAC per leaf)
 #   dgrad   : every layer but the first conv (transposed convs on the forward kernels: the same MACs), folded tail through the
 #             transposed operator 1.835 M                                                                    = 27.39 M MAC
 #   wgrad   : every conv layer (dW = sum over leaves and positions of dY X^T: the forward's MACs), folded tail 1.835 M = 27.56 M MAC
-TRAIN_ISSUED_FLOP = {"forward": 2 * 29.39e6, "dgrad": 2 * 27.39e6, "wgrad": 2 * 27.56e6}
+TRAIN_ISSUED_FLOP = {"forward": 2 * 21.20e6, "dgrad": 2 * 27.39e6, "wgrad": 2 * 27.56e6}
 
 
 def train_step_classes(codec, step_fn, leaves, device, steps=3):

@@ -51,6 +51,24 @@ def test_training_forward_matches_torch(fcodec, ref, weights):
     assert np.array_equal(q, E[idx].transpose(0, 2, 1))
 
 
+def test_stem_table_kernels_agree(fcodec, ref, weights, oracle):
+    """The training forward runs the decoder stem through a (tap, code) table rebuilt every step on the matrix pipe
+    (build_stem_lut_mfma_k); inference builds the same table once with build_stem_lut_k.  Same fmaf chains ("P8" from zero), so the
+    stem output of the training forward must equal the oracle's decoder stem (= the inference kernels') BIT FOR BIT on the codes
+    the training forward assigned."""
+    from oracle.oracle import DEC_DEBUG
+    x = torch.from_numpy(ref["x"]).cuda()
+    fcodec.fulltrain_forward_device(x.data_ptr(), N)
+    torch.cuda.synchronize()
+    q = fcodec.fetch("t_q", N, 128, 64)                               # gathered codebook rows [N, 128, 64]
+    E = weights["quantizer.embedding"]
+    rows = q.transpose(0, 2, 1).reshape(-1, 128)
+    idx = np.array([int(np.nonzero((E == r).all(axis=1))[0][0]) for r in rows], dtype=np.uint8).reshape(N, 64)
+    _, dbg = oracle.decode(idx, threads=8, debug=DEC_DEBUG)
+    got = fcodec.fetch("d_ystem", N, 64, 64)
+    assert np.array_equal(np.where(got == 0, 0.0, got).view(np.uint32), np.where(dbg["d_ystem"] == 0, 0.0, dbg["d_ystem"]).view(np.uint32))
+
+
 @pytest.fixture(scope="module")
 def ref_grads(weights):
     torch.set_num_threads(16)

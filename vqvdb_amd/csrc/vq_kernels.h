@@ -1547,6 +1547,33 @@ __global__ __launch_bounds__(64) void build_stem_lut_k(const float* __restrict__
     T[((size_t)tap * 256 + k) * 64 + co] = p;
 }
 
+// The same table on the matrix pipe (training: the table follows the weights AND the codebook, every step): one wave per (tap, cout
+// tile of 32, code tile of 32), A = the stem's forward fragments (frag32: [tap][u 16][mt 2][lane][4]), B = codebook rows.  The K order
+// of a 32x32x2 chain over u, i is 8u+i, 8u+4+i — "P8", the order of build_stem_lut_k's fmaf chain — so the two kernels agree bit for
+// bit (tests/test_gpu_fulltrain.py::test_stem_table_kernels_agree); 0.17 ms -> a few microseconds.
+__global__ __launch_bounds__(64) void build_stem_lut_mfma_k(const float* __restrict__ wfrag, const float* __restrict__ E /*[256][128]*/,
+                                                            float* __restrict__ T /*[27][256][64]*/)
+{
+    const int tap = blockIdx.x >> 4, mt = blockIdx.x & 1, ct = (blockIdx.x >> 1) & 7;
+    const int lane = threadIdx.x, j = lane & 31, q = lane >> 5;
+    const f32x4* a4 = (const f32x4*)wfrag + ((size_t)tap * 16 * 2 + mt) * 64 + lane;   // + u * 2 * 64
+    const f32x4* b4 = (const f32x4*)E + (size_t)(ct * 32 + j) * 32 + q;                 // + 2u
+    f32x16 d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const f32x4 a = a4[u * 2 * 64], b = b4[2 * u];
+        d = mfma32(a.x, b.x, d);
+        d = mfma32(a.y, b.y, d);
+        d = mfma32(a.z, b.z, d);
+        d = mfma32(a.w, b.w, d);
+    }
+    float* t = T + ((size_t)tap * 256 + ct * 32 + j) * 64 + 32 * mt + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[(r & 3) + 8 * (r >> 2)] = d[r];
+}
+
 __global__ __launch_bounds__(256) void stem_lut_k(const uint8_t* __restrict__ idx, const float* __restrict__ T, const float* __restrict__ bias,
                                                   float* __restrict__ out, float* __restrict__ out_mean, float* __restrict__ out_rstd,
                                                   const int4* __restrict__ steps, int n_steps, int64_t n_leaves, int n_tiles,
