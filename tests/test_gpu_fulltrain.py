@@ -12,6 +12,7 @@ from vqvdb_amd.codec import HipCodec
 pytestmark = pytest.mark.gpu
 N = 40   # two tiles, the second one ragged
 TOL_GRAD = 5e-4   # parameter gradients are long fp32 sums with cancellation on both sides (HIP and torch)
+GRAD_VS_FP64 = 5e-6   # ... measured against the same step in fp64 on a batch without ReLU-boundary hits: 4.1e-7 (test_parameter_gradients_against_fp64_autograd)
 
 
 def _rel(a, b):
@@ -122,6 +123,47 @@ def test_encoder_gradients_match_autograd(fcodec, ref_grads, weights):
     assert _rel(fcodec.fetch("g16b", N, 16, 512), tape["e.y1"].grad.numpy().reshape(N, 16, 512)) < 1e-4
     bad = [(name, _rel(g, ref_grads["w"][name].grad.numpy())) for name, g in got.items() if name.startswith("encoder.")]
     assert all(e < TOL_GRAD for _, e in bad), [b for b in bad if b[1] >= TOL_GRAD]
+
+
+def test_parameter_gradients_against_fp64_autograd(fcodec, weights):
+    """What TOL_GRAD = 5e-4 hides (the loosest bar of the suite).  Parameter gradients are fp32 sums over 40 leaves x up to
+    512 positions with heavy cancellation, evaluated in different orders by the HIP kernels and by PyTorch — so both are measured
+    here against the SAME step in fp64 (tests/torch_ref.py on double tensors).  Two discontinuities are kept out of the comparison,
+    because no bar on rounding can cover them: the code assignment (an fp32 near-tie) and the ReLU masks — the shared fixture's batch
+    (seed 6000) has ONE decoder pre-activation 2.8e-8 from zero, whose mask flips between two fp32 evaluations and moves
+    decoder.res_stack.0.gn1.bias' gradient by 1.9e-4 of its max (every other tensor of that batch: <= 1.8e-5).  The batch used here
+    is the first seed whose fp64 forward keeps every ReLU input at least 2e-6 from zero (an order of magnitude above fp32 rounding of these O(1) values) and assigns the fp32 codes.  Bar: every
+    parameter gradient within GRAD_VS_FP64 of the fp64 gradient, relative to the tensor's max (PyTorch's own fp32 gradients printed
+    beside)."""
+    import torch.nn.functional as F
+    torch.set_num_threads(16)
+    real_relu, seen = F.relu, []
+
+    def spy(t, *a, **k):
+        seen.append(float(t.detach().abs().min()))
+        return real_relu(t, *a, **k)
+    for seed in range(6100, 6140):
+        x = synth.make_leaves(N, seed=seed)
+        w64 = {k: torch.as_tensor(v, dtype=torch.float64).clone().requires_grad_(not k.startswith("quantizer.")) for k, v in weights.items()}
+        seen.clear()
+        F.relu = spy
+        try:
+            loss64, pieces64 = torch_ref.training_loss(torch.as_tensor(x, dtype=torch.float64).view(-1, 1, 8, 8, 8), w64)
+        finally:
+            F.relu = real_relu
+        w32 = {k: torch.as_tensor(v).clone().requires_grad_(not k.startswith("quantizer.")) for k, v in weights.items()}
+        loss32, pieces32 = torch_ref.training_loss(torch.as_tensor(x).view(-1, 1, 8, 8, 8), w32)
+        if min(seen) > 2e-6 and torch.equal(pieces64["idx"], pieces32["idx"]):
+            break
+    else:
+        pytest.fail("no batch without a ReLU input within 2e-6 of zero")
+    loss64.backward()
+    loss32.backward()
+    got = _hip_grads(fcodec, weights, x)
+    worst = sorted(((_rel(g, w64[name].grad.numpy()), name, _rel(w32[name].grad.numpy(), w64[name].grad.numpy())) for name, g in got.items()), reverse=True)
+    print(f"seed {seed} (closest ReLU input to zero {min(seen):.1e}): parameter gradients vs fp64 autograd, relative to each tensor's max — largest HIP "
+          "errors (HIP, torch fp32):", [(n, f"{a:.1e}", f"{b:.1e}") for a, n, b in worst[:8]])
+    assert worst[0][0] < GRAD_VS_FP64, worst[:4]
 
 
 def test_three_optimizer_steps_match_torch(weights):
