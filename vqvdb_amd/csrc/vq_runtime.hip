@@ -929,6 +929,23 @@ int init_kernel_attrs(vqhip_codec* c)
     return VQHIP_OK;
 }
 
+// Where the encoder's GroupNorm statistics and channel sums live.  Inference ping-pongs two buffers (st_a / st_b); the full training
+// step needs every layer's statistics again in its backward pass, so there each tensor's statistics go to their own buffer of the
+// training workspace (ts_*) — the forward used to overwrite them and a pass of six sequential statistics kernels recomputed them
+// from the stored activations (0.17 ms of a 7 ms step).
+struct EncStats {
+    float *y1m, *y1r, *a1m, *a1r, *y4m, *y4r, *x7m, *x7r, *y9m, *y9r, *csum;
+};
+EncStats enc_stats_of(vqhip_codec* c)
+{
+    auto& a = c->act;
+    if (c->full_training && c->keep_y1)
+        return {a["ts_gn0.mean"], a["ts_gn0.rstd"], a["ts_r16g1.mean"], a["ts_r16g1.rstd"], a["ts_r16g2.mean"], a["ts_r16g2.rstd"],
+                a["ts_r32g1.mean"], a["ts_r32g1.rstd"], a["ts_r32g2.mean"], a["ts_r32g2.rstd"], a["ts_ecsum"]};
+    return {a["st_a.mean"], a["st_a.rstd"], a["st_b.mean"], a["st_b.rstd"], a["st_a.mean"], a["st_a.rstd"],
+            a["st_b.mean"], a["st_b.rstd"], a["st_a.mean"], a["st_a.rstd"], a["csum"]};
+}
+
 void launch_latent_assign(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, float* d_latent, hipStream_t s, int split)
 {
     auto& a = c->act;
@@ -937,7 +954,7 @@ void launch_latent_assign(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx
     // training forward: latent materialised, reference-faithful distance against the live codebook
     L.run("train_codebook_frag", [&] { hipLaunchKernelGGL(codebook_frag_k, dim3(33), dim3(256), 0, s, w["cb"], w["tr.efrag"], w["tr.ee"]); });
     LatentArgs A{};
-    A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+    A.in = a["e_x11"], A.se_csum = enc_stats_of(c).csum, A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
     A.wproj = w["tr.wproj"], A.bproj = w["tr.bproj"], A.efrag = w["tr.efrag"], A.ee_frag = w["tr.ee"];
     A.idx = d_idx, A.z = d_latent, A.z4 = c->z4_out, A.n_leaves = n, A.n_tiles = nt;
     if (split <= 1 && nt >= 1024) L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<8>, dim3((nt + 7) / 8), dim3(512), LDS_LATENT, s, A); });
@@ -973,6 +990,7 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
     const int nt = (int)((n + 31) / 32);
     auto& a = c->act;
     auto& w = c->dw;
+    EncStats S = enc_stats_of(c);
     auto od = [&](const char* name) { return reinterpret_cast<const int*>(w[std::string(name) + ".grp"]); };
     const int g4 = (nt + 3) / 4, g2 = (nt + 1) / 2, gh = (2 * nt + 7) / 8;   // gh: workgroups of 8 half tiles (conv_rows16_k)
     double* ps = reinterpret_cast<double*>(a["part_s"]);
@@ -989,26 +1007,26 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         const int psf = split_factor(g4, 8, 16, 1024);
         L.run("enc_conv_first_stats_s", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
-        combine("enc_stats_y1", 4, 1.0 / 2048.0, a["st_a.mean"], a["st_a.rstd"]);
-        A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
+        combine("enc_stats_y1", 4, 1.0 / 2048.0, S.y1m, S.y1r);
+        A.out = a["e_a1"], A.in_mean = S.y1m, A.in_rstd = S.y1r, A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
         L.run("enc_conv_first_gn_s", [&] { hipLaunchKernelGGL(conv_first_k<1>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
-        combine("enc_stats_a1", 8, 1.0 / 1024.0, a["st_b.mean"], a["st_b.rstd"]);
+        combine("enc_stats_a1", 8, 1.0 / 1024.0, S.a1m, S.a1r);
     } else {
         ConvArgs A{};
         A.in = a["xr"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
-        combine("enc_stats_y1", 4, 1.0 / 2048.0, a["st_a.mean"], a["st_a.rstd"]);
+        combine("enc_stats_y1", 4, 1.0 / 2048.0, S.y1m, S.y1r);
         ConvArgs B{};
-        B.in = a["e_y1"], B.out = a["e_a1"], B.in_mean = a["st_a.mean"], B.in_rstd = a["st_a.rstd"], B.in_gamma = w["eg0.w"], B.in_beta = w["eg0.b"];
+        B.in = a["e_y1"], B.out = a["e_a1"], B.in_mean = S.y1m, B.in_rstd = S.y1r, B.in_gamma = w["eg0.w"], B.in_beta = w["eg0.b"];
         B.n_tiles = nt, B.part_s = ps, B.part_q = pq;
         L.run("enc_gn_relu_a1", [&] { hipLaunchKernelGGL((gn_relu_stats_k<16, 512, 4>), dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, B); });
-        combine("enc_stats_a1", 8, 1.0 / 1024.0, a["st_b.mean"], a["st_b.rstd"]);
+        combine("enc_stats_a1", 8, 1.0 / 1024.0, S.a1m, S.a1r);
     }
     {
         ConvArgs A{};
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
-        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
+        A.in_mean = S.a1m, A.in_rstd = S.a1r, A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"], A.n_tiles = nt;
         const int gq = (2 * nt + 3) / 4;
         // conv1 carries the statistics.  This tensor's statistics blocks are its 128 output half rows: 2 x 1024 doubles per leaf of
         // partials, which live in the region of conv2's output (e_a6: free until conv2 runs, after the combine)
@@ -1023,10 +1041,10 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
             if (two) hipLaunchKernelGGL((conv8_c16_k<2, false, true>), dim3(gq, 32), dim3(256), 0, s, A, (const int4*)w[tab]);
             else hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w[tab]);
         });
-        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, psr, pqr, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+        L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, psr, pqr, S.y4m, S.y4r, 8, 1.0 / 1024.0); });
         A.part_s = nullptr, A.part_q = nullptr;
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
-        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
+        A.in_mean = S.y4m, A.in_rstd = S.y4r, A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"];
         L.run("enc_res16_conv2_s", [&] {
             if (two) hipLaunchKernelGGL((conv8_c16_k<2, true, false>), dim3(gq, 32), dim3(256), 0, s, A, (const int4*)w[tab]);
             else hipLaunchKernelGGL((conv8_c16_k<4, true, false>), dim3(gq, split_factor(gq, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w[tab]);
@@ -1041,12 +1059,12 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
             if (gh * psr * 2 <= 256) hipLaunchKernelGGL(k_enc_down_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_DOWN_R / 2, s, A, (const int4*)w["steps.rows_k4s2_8"]);
             else hipLaunchKernelGGL(k_enc_down_rs, dim3(gh, psr), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]);
         });
-        combine("enc_stats_x7", 8, 1.0 / 256.0, a["st_b.mean"], a["st_b.rstd"]);
+        combine("enc_stats_x7", 8, 1.0 / 256.0, S.x7m, S.x7r);
     }
     {
         ConvArgs A{};
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w16"], A.bias_frag = w["r32c1.braw"];
-        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
+        A.in_mean = S.x7m, A.in_rstd = S.x7r, A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27, A.grp_start = od("steps.rows_k3_4"), A.part_s = ps, A.part_q = pq;
         const int psr = split_factor(gh, 4, 16, 512);
         const bool ms = gh * psr * 2 <= 256;   // up to 1024 leaves (measured): also split the 32 couts over gridDim.z
@@ -1054,22 +1072,22 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
             if (ms) hipLaunchKernelGGL(k_enc_r32c1_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_enc_r32c1_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        combine("enc_stats_y9", 8, 1.0 / 256.0, a["st_a.mean"], a["st_a.rstd"]);
+        combine("enc_stats_y9", 8, 1.0 / 256.0, S.y9m, S.y9r);
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w16"], A.bias_frag = w["r32c2.braw"], A.skip = a["e_x7"];
-        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
+        A.in_mean = S.y9m, A.in_rstd = S.y9r, A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
         A.part_s = nullptr, A.part_q = nullptr, A.part_c = a["part_c"];
         L.run("enc_res32_conv2_s", [&] {
             if (ms) hipLaunchKernelGGL(k_enc_r32c2_rs2, dim3(gh, psr, 2), dim3(512), LDS_ENC_R32R / 2, s, A, (const int4*)w["steps.rows_k3_4"]);
             else hipLaunchKernelGGL(k_enc_r32c2_rs, dim3(gh, psr), dim3(512), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]);
         });
-        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_combine_k<32>), dim3(nt), dim3(256), 0, s, a["part_c"], a["csum"], w["efc0"], w["efc2"], a["gate"]); });
+        L.run("enc_csum_x11", [&] { hipLaunchKernelGGL((csum_combine_k<32>), dim3(nt), dim3(256), 0, s, a["part_c"], S.csum, w["efc0"], w["efc2"], a["gate"]); });
     }
     if (d_latent) {
         launch_latent_assign(c, L, n, d_idx, d_latent, s, split_factor(g2, 8, 32, 512));
         return L.rc;
     }
     VqArgs A{};
-    A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+    A.in = a["e_x11"], A.se_csum = S.csum, A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
     A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
     A.se_gate = a["gate"];   // computed once per tile by enc_csum_x11
     L.run("enc_vq_s", [&] {
@@ -1089,6 +1107,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     auto& w = c->dw;
     Launcher L{c, s, n};
     const int g4 = (nt + 3) / 4, g8 = (nt + 7) / 8;
+    EncStats S = enc_stats_of(c);
 
     // the position-major copy xt is only read by the training step (loss, first-conv weight gradients) and by debug fetches
     float* xt = (c->training || c->full_training || c->debug) ? a["xt"] : nullptr;
@@ -1098,33 +1117,33 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
         A.in = a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
-        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
+        A.out_mean = S.y1m, A.out_rstd = S.y1r, A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
         L.run("enc_conv_first_stats", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
-        A.out = a["e_a1"], A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
-        A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"];
+        A.out = a["e_a1"], A.in_mean = S.y1m, A.in_rstd = S.y1r, A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
+        A.out_mean = S.a1m, A.out_rstd = S.a1r;
         L.run("enc_conv_first_gn", [&] { hipLaunchKernelGGL(conv_first_k<1>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_a1"], A.out = a["e_y4"], A.wfrag = w["r16c1.w"], A.bias_frag = w["r16c1.b"];
-        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
-        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        A.in_mean = S.a1m, A.in_rstd = S.a1r, A.in_gamma = w["r16g1.w"], A.in_beta = w["r16g1.b"];
+        A.out_mean = S.y4m, A.out_rstd = S.y4r, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rowgroups8_4"];
         if (c->conv8_lds) {   // input planes staged in LDS by a persistent workgroup per CU; statistics as 16 half-row totals + combine
             A.part_s = reinterpret_cast<double*>(a["part_s"]), A.part_q = reinterpret_cast<double*>(a["part_q"]);
             if (c->conv8_w16) L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_lds_k<false, true, 16, 0, false>), dim3(std::min(2 * nt, c->n_cus)), dim3(1024), LDS_CONV8, s, A); });
             else L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_lds_k<false, true, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
-            L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+            L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, S.y4m, S.y4r, 8, 1.0 / 1024.0); });
         } else {   // row-group kernel: one partial per output half row (in the region of conv2's output, free until then), added row-major by the combine
             A.part_s = reinterpret_cast<double*>(a["e_a6"]), A.part_q = A.part_s + (size_t)nt * 128 * 8 * 32;
             L.run("enc_res16_conv1", [&] { hipLaunchKernelGGL((conv8_c16_k<4, false, true>), dim3((2 * nt + 3) / 4), dim3(256), 0, s, A, (const int4*)w["steps.rowgroups8_4"]); });
-            L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, a["st_a.mean"], a["st_a.rstd"], 8, 1.0 / 1024.0); });
+            L.run("enc_stats_y4", [&] { hipLaunchKernelGGL((gn_combine_k<false, true>), dim3(nt), dim3(8 * 32), 0, s, A.part_s, A.part_q, S.y4m, S.y4r, 8, 1.0 / 1024.0); });
         }
     }
     {
         ConvArgs A{};
         A.in = a["e_y4"], A.out = a["e_a6"], A.wfrag = w["r16c2.w"], A.bias_frag = w["r16c2.b"], A.skip = a["e_a1"];
-        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
+        A.in_mean = S.y4m, A.in_rstd = S.y4r, A.in_gamma = w["r16g2.w"], A.in_beta = w["r16g2.b"], A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rowgroups8_4"];
         if (c->conv8_lds && c->conv8_w16) L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_lds_k<true, false, 16, 0, false>), dim3(std::min(2 * nt, c->n_cus)), dim3(1024), LDS_CONV8, s, A); });
         else if (c->conv8_lds) L.run("enc_res16_conv2", [&] { hipLaunchKernelGGL((conv8_lds_k<true, false, 8, 0, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV8, s, A); });
@@ -1133,23 +1152,23 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     {
         ConvArgs A{};
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"];
-        A.out_mean = a["st_b.mean"], A.out_rstd = a["st_b.rstd"], A.n_tiles = nt;
+        A.out_mean = S.x7m, A.out_rstd = S.x7r, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64;
         L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_x7"], A.out = a["e_y9"], A.wfrag = w["r32c1.w16"], A.bias_frag = w["r32c1.braw"];
-        A.in_mean = a["st_b.mean"], A.in_rstd = a["st_b.rstd"], A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
-        A.out_mean = a["st_a.mean"], A.out_rstd = a["st_a.rstd"], A.n_tiles = nt;
+        A.in_mean = S.x7m, A.in_rstd = S.x7r, A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
+        A.out_mean = S.y9m, A.out_rstd = S.y9r, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
         L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
         ConvArgs A{};
         A.in = a["e_y9"], A.out = a["e_x11"], A.wfrag = w["r32c2.w16"], A.bias_frag = w["r32c2.braw"], A.skip = a["e_x7"];
-        A.in_mean = a["st_a.mean"], A.in_rstd = a["st_a.rstd"], A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
-        A.out_csum = a["csum"], A.n_tiles = nt;
+        A.in_mean = S.y9m, A.in_rstd = S.y9r, A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
+        A.out_csum = S.csum, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
         L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
@@ -1160,7 +1179,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
     }
     {
         VqArgs A{};
-        A.in = a["e_x11"], A.se_csum = a["csum"], A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
+        A.in = a["e_x11"], A.se_csum = S.csum, A.se_fc0 = w["efc0"], A.se_fc2 = w["efc2"];
         A.epfrag = w["vq.ep"], A.ck_frag = w["vq.ck"], A.idx = d_idx, A.n_leaves = n, A.n_tiles = nt;
         // two position ranges per tile: 2 x n_tiles waves = 4 per SIMD on a full chunk (one wave per tile leaves 2, and the wave's
         // MFMA chain -> argmin scan -> next chain sequence has nobody to overlap with)
