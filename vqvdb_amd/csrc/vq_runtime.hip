@@ -926,6 +926,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, stem_taps_k, LDS_STEM_TAPS))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
+    if ((rc = set_lds(c, latent_assign_k<4>, LDS_LATENT))) return rc;
     return VQHIP_OK;
 }
 
@@ -958,7 +959,12 @@ void launch_latent_assign(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx
     A.wproj = w["tr.wproj"], A.bproj = w["tr.bproj"], A.efrag = w["tr.efrag"], A.ee_frag = w["tr.ee"];
     A.idx = d_idx, A.z = d_latent, A.z4 = c->z4_out, A.n_leaves = n, A.n_tiles = nt;
     if (split <= 1 && nt >= 1024) L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<8>, dim3((nt + 7) / 8), dim3(512), LDS_LATENT, s, A); });
-    else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2, split > 1 ? split : 1), dim3(128), LDS_LATENT, s, A); });
+    else if (split > 1 && nt >= 8) {
+        // small training batches: 144 KB of LDS = one workgroup per CU, so FOUR waves per workgroup (every SIMD busy; two left half of
+        // the CU idle) and twice the position ranges: 0.236 -> 0.13 ms at 2048 leaves
+        const int sp = std::min(64, 2 * split);
+        L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<4>, dim3((nt + 3) / 4, sp), dim3(256), LDS_LATENT, s, A); });
+    } else L.run("train_latent_assign", [&] { hipLaunchKernelGGL(latent_assign_k<2>, dim3((nt + 1) / 2, split > 1 ? split : 1), dim3(128), LDS_LATENT, s, A); });
 }
 
 // gridDim.y for a position-split launch of `wgs` workgroups: enough ranges to reach `target` workgroups (about two rounds
