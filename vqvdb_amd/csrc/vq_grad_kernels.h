@@ -336,8 +336,8 @@ struct WgradArgs {
     int n_tiles, tiles_per_group, KT;
 };
 
-#ifndef WGRAD_NS_OVERRIDE
-#define WGRAD_NS_OVERRIDE 0
+#ifndef WGRAD_ABL   // timing-only switches of tools/ablate/wgrad_ablate.hip: 1 one global fetch only, 2 no MFMAs, 4 no LDS staging / barriers
+#define WGRAD_ABL 0
 #endif
 template <int CIN, int COUT, int NPI, int NPO, int INMODE, int GIN>
 __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void wgrad32_k(WgradArgs A)
@@ -347,22 +347,33 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
     constexpr bool SMALL = CIN == 16;
     constexpr int CB = SMALL ? 1 : (COUT + 31) / 32, IB = SMALL ? 1 : (CIN + 31) / 32, NT = CB * IB * 64;
     constexpr int ROWS_DY = SMALL ? COUT : CB * 32, ROWS_X = SMALL ? 16 : IB * 32;
-    // position pairs staged per pair of barriers.  One: two were measured 4-10 % SLOWER for the 32x32x2 layers (half the barriers, but
-    // twice the LDS footprint and a longer serial stage -> MFMA phase per workgroup), 4 for the 16-channel layers 2x slower.
-    constexpr int NS = WGRAD_NS_OVERRIDE > 0 ? WGRAD_NS_OVERRIDE : 1;
     // blocks in LDS as [leaf][channel] (round 2; [channel][leaf] before): a thread's float4 = 4 channels of one leaf goes in with ONE
     // 16-byte write instead of four scalar ones; the MFMA operands A[row = channel][k = leaf] are read row-wise over the channels
     // (consecutive banks).  Row stride +4 floats: the 32 leaves of a write land on 8 bank groups instead of one.
+    // Two buffers (round 3): the blocks of pair i+1 are written while the MFMAs of pair i read the other buffer — ONE barrier per pair
+    // (two before, with the staging and the MFMA phase of a workgroup strictly alternating: 20 % of the launch by ablation,
+    // tools/ablate/wgrad_ablate.hip).
     constexpr int SDY = ROWS_DY + 4, SX = ROWS_X + 4;
-    __shared__ __attribute__((aligned(16))) float sdy[NS][32][SDY];
-    __shared__ __attribute__((aligned(16))) float sx[NS][32][SX];
-    for (int i = threadIdx.x; i < NS * 32 * SDY; i += NT) (&sdy[0][0][0])[i] = 0.0f;
-    for (int i = threadIdx.x; i < NS * 32 * SX; i += NT) (&sx[0][0][0])[i] = 0.0f;
-    const int tap = blockIdx.x, grp = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float sdy[2][32][SDY];
+    __shared__ __attribute__((aligned(16))) float sx[2][32][SX];
+    for (int i = threadIdx.x; i < 2 * 32 * SDY; i += NT) (&sdy[0][0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < 2 * 32 * SX; i += NT) (&sx[0][0][0])[i] = 0.0f;
+    // Workgroup -> (tap, chunk, tile group), XCD-aware: the dispatcher is observed to place workgroup b on XCD b % 8 (a speed assumption only), so
+    // the linear id is remapped to give every XCD a contiguous range of (group, chunk, tap) with the tap fastest: all taps of a tile group run
+    // on one XCD at the same time and re-read the group's dY / X blocks from that XCD's L2 instead of 27 x from the fabric.
+    int tap, grp, chunk;
+    {
+        const int n = gridDim.x * gridDim.y * gridDim.z, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = lin & 7, q = n >> 3, r = n & 7;
+        const int virt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        tap = virt % (int)gridDim.x;
+        chunk = (virt / (int)gridDim.x) % (int)gridDim.z;
+        grp = virt / (int)(gridDim.x * gridDim.z);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
     // the tap's (ip, po) pairs are cut into gridDim.z chunks (more workgroups for the small layers)
     const int t_s0 = A.tap_start[tap], t_s1 = A.tap_start[tap + 1];
-    const int s0 = t_s0 + (int)((int64_t)(t_s1 - t_s0) * blockIdx.z / gridDim.z), s1 = t_s0 + (int)((int64_t)(t_s1 - t_s0) * (blockIdx.z + 1) / gridDim.z);
+    const int s0 = t_s0 + (int)((int64_t)(t_s1 - t_s0) * chunk / gridDim.z), s1 = t_s0 + (int)((int64_t)(t_s1 - t_s0) * (chunk + 1) / gridDim.z);
     const int t0 = grp * A.tiles_per_group, t1 = min(A.n_tiles, t0 + A.tiles_per_group);
     f32x16 acc;
     f32x4 acc16[SMALL ? COUT / 16 : 1];
@@ -371,34 +382,36 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
 #pragma unroll
     for (int b = 0; b < (SMALL ? COUT / 16 : 1); ++b) acc16[b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
-    // One GROUP = up to NS consecutive position pairs of one tile (a group never straddles tiles: the input transform is per tile).
-    // The group's dY / X blocks are requested one group AHEAD into registers: the loads of group g+1 are in flight while group g's
-    // MFMAs run.  Tile / group counters advance incrementally (no division by the run-time pair count in the loop).
+    // The dY / X blocks of one position pair of one tile are requested TWO pairs ahead into registers (in flight during a whole MFMA phase),
+    // written to LDS one pair ahead.  Tile / pair counters advance incrementally (no division by the run-time pair count in the loop).
     constexpr int ND = ((COUT / 4) * 32 + NT - 1) / NT, NX = ((CIN / 4) * 32 + NT - 1) / NT;
-    const int npairs = s1 - s0, ngr = (npairs + NS - 1) / NS;
-    f32x4 rdy[NS][ND], rx[NS][NX];
-    int ft = t0, fg = 0;   // next group to request
+    const int npairs = s1 - s0;
+    const int total = npairs > 0 && t1 > t0 ? npairs * (t1 - t0) : 0;
+    f32x4 rdy[ND], rx[NX];
+    int ft = t0, fg = 0;   // next pair to request
+    bool fetched = false;
     // (buffer addressing, see buf_ld16: the block of a position is one contiguous run, thread i takes float4 i)
-    auto fetch_group = [&]() {
+    auto fetch_pair = [&]() {
         if (ft >= t1 || npairs <= 0) return;   // (uniform)
+        if ((WGRAD_ABL & 1) && fetched) {
+            if (++fg == npairs) fg = 0, ++ft;
+            return;
+        }
+        fetched = true;
         const vq_buf dyb = buf_of((const f32x4*)A.dy + (size_t)ft * NPO * (COUT / 4) * 32);
         const vq_buf xb = buf_of((const f32x4*)A.x + (size_t)ft * NPI * (CIN / 4) * 32);
+        const int2 e = A.wsteps[s0 + fg];   // x = input position, y = output position
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (fg * NS + sl >= npairs) continue;   // (uniform)
-            const int2 e = A.wsteps[s0 + fg * NS + sl];   // x = input position, y = output position
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const int i = threadIdx.x + d * NT;
-                if (i < (COUT / 4) * 32) rdy[sl][d] = buf_ld16(dyb, (unsigned)i * 16u, (unsigned)e.y * (COUT / 4) * 512u);
-            }
-#pragma unroll
-            for (int d = 0; d < NX; ++d) {
-                const int i = threadIdx.x + d * NT;
-                if (i < (CIN / 4) * 32) rx[sl][d] = buf_ld16(xb, (unsigned)i * 16u, (unsigned)e.x * (CIN / 4) * 512u);
-            }
+        for (int d = 0; d < ND; ++d) {
+            const int i = threadIdx.x + d * NT;
+            if (i < (COUT / 4) * 32) rdy[d] = buf_ld16(dyb, (unsigned)i * 16u, (unsigned)e.y * (COUT / 4) * 512u);
         }
-        if (++fg == ngr) fg = 0, ++ft;
+#pragma unroll
+        for (int d = 0; d < NX; ++d) {
+            const int i = threadIdx.x + d * NT;
+            if (i < (CIN / 4) * 32) rx[d] = buf_ld16(xb, (unsigned)i * 16u, (unsigned)e.x * (CIN / 4) * 512u);
+        }
+        if (++fg == npairs) fg = 0, ++ft;
     };
     // the input transform of this thread's channels (GroupNorm scale / shift or attention gate): per (tile, channel, leaf), so it
     // changes only when the tile does — it used to be re-loaded in every step, 8-16 scalar loads per 16 MFMAs
@@ -423,59 +436,63 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
             }
         }
     };
-    fetch_group();
-    int cg = 0;
-    for (int ct = t0; ct < t1 && npairs > 0;) {
-        // one group: its blocks (in registers) -> LDS ([leaf][channel], GroupNorm+ReLU / gate applied to X on the way), request the next
-        // group into the registers just freed, MFMAs pair by pair in ascending order
-        if (INMODE != 0 && cg == 0) load_transform(ct);   // (uniform)
-        const int nvalid = min(NS, npairs - cg * NS);
-        __syncthreads();              // previous group's MFMAs have read the blocks
+    // the requested pair (in registers) -> LDS buffer `buf` ([leaf][channel], GroupNorm+ReLU / gate applied to X on the way)
+    int wt = t0, wp = 0;   // tile / pair being written
+    auto stage = [&](int buf) {
+        if (INMODE != 0 && wp == 0) load_transform(wt);   // (uniform)
+        if (++wp == npairs) wp = 0, ++wt;
+        if (WGRAD_ABL & 4) return;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (sl >= nvalid) continue;   // (uniform)
+        for (int dd = 0; dd < ND; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (COUT / 4) * 32) *(f32x4*)&sdy[buf][i & 31][4 * (i >> 5)] = rdy[dd];
+        }
 #pragma unroll
-            for (int dd = 0; dd < ND; ++dd) {
-                const int i = threadIdx.x + dd * NT;
-                if (i < (COUT / 4) * 32) *(f32x4*)&sdy[sl][i & 31][4 * (i >> 5)] = rdy[sl][dd];
-            }
+        for (int dd = 0; dd < NX; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (CIN / 4) * 32) {
+                const int quad = i >> 5, leaf = i & 31;
+                const f32x4 v = rx[dd];
+                float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int dd = 0; dd < NX; ++dd) {
-                const int i = threadIdx.x + dd * NT;
-                if (i < (CIN / 4) * 32) {
-                    const int quad = i >> 5, leaf = i & 31;
-                    const f32x4 v = rx[sl][dd];
-                    float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        if (INMODE == 1) o[kk] = fmaxf(__builtin_fmaf(o[kk], tia[dd][kk], tib[dd][kk]), 0.0f);
-                        else if (INMODE == 2) o[kk] = o[kk] * tia[dd][kk];
-                    }
-                    *(f32x4*)&sx[sl][leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (INMODE == 1) o[kk] = fmaxf(__builtin_fmaf(o[kk], tia[dd][kk], tib[dd][kk]), 0.0f);
+                    else if (INMODE == 2) o[kk] = o[kk] * tia[dd][kk];
                 }
+                *(f32x4*)&sx[buf][leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
             }
         }
-        if (++cg == ngr) cg = 0, ++ct;
-        fetch_group();   // in flight during this group's MFMAs
-        __syncthreads();
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            if (sl >= nvalid) continue;   // (uniform)
+    };
+    fetch_pair();
+    __syncthreads();   // the zero fill
+    if (total > 0) {
+        stage(0);
+        fetch_pair();
+    }
+    __syncthreads();
+    for (int i = 0; i < total; ++i) {
+        const int buf = i & 1;
+        if (i + 1 < total) {   // (uniform)
+            stage(buf ^ 1);    // every wave has left the MFMAs of pair i-1, which read that buffer (barrier below)
+            fetch_pair();      // pair i+2: in flight during this pair's MFMAs and the next one's
+        }
+        if (!(WGRAD_ABL & 2)) {
             if (SMALL) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const float bx = sx[sl][4 * m + (lane >> 4)][lane & 15];
+                    const float bx = sx[buf][4 * m + (lane >> 4)][lane & 15];
 #pragma unroll
-                    for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[sl][4 * m + (lane >> 4)][16 * b + (lane & 15)], bx, acc16[b]);
+                    for (int b = 0; b < COUT / 16; ++b) acc16[b] = mfma16(sdy[buf][4 * m + (lane >> 4)][16 * b + (lane & 15)], bx, acc16[b]);
                 }
             } else {
 #pragma unroll
                 for (int m = 0; m < 16; ++m)
-                    acc = mfma32(sdy[sl][2 * m + (lane >> 5)][32 * cb + (lane & 31)], sx[sl][2 * m + (lane >> 5)][32 * ib + (lane & 31)], acc);
+                    acc = mfma32(sdy[buf][2 * m + (lane >> 5)][32 * cb + (lane & 31)], sx[buf][2 * m + (lane >> 5)][32 * ib + (lane & 31)], acc);
             }
         }
+        if (!(WGRAD_ABL & 4)) __syncthreads();
     }
-    float* dst = A.part + (((size_t)grp * gridDim.z + blockIdx.z) * A.KT + tap) * COUT * CIN;
+    float* dst = A.part + (((size_t)grp * gridDim.z + chunk) * A.KT + tap) * COUT * CIN;
     if (SMALL) {
 #pragma unroll
         for (int b = 0; b < COUT / 16; ++b) {
@@ -550,6 +567,225 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
         float s = 0.0f;
         for (int g = 0; g < n_groups; ++g) s += part[(((size_t)g * KT + tap) * COUT + co) * CIN + ci];
         dW[((size_t)(row0 + co) * IC + ci) * KT + tap] = scale * s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the k3 p1 layers at 4^3 with a rolling window along W (round 3).  wgrad32_k stages one dY block and one X' block per
+// position pair and spends 16 MFMAs per wave on them: 192-512 bytes through LDS per MFMA, and by ablation (tools/ablate/wgrad_ablate.hip)
+// 25 % of its time goes to fetching and staging, another 20 % to the unequal pair counts of the taps (27 ... 64) with every workgroup
+// resident at once.  Here a workgroup keeps (kd, kh) fixed ("class", 9 of them) and walks row pairs (od, oh) -> (id, ih) = (od+kd-1, oh+kh-1);
+// step j = 0..3 of a row pair stages dY[ow = j] and X'[iw = j] into a ring of three LDS slots and multiplies
+//     dY[j]^T X'[j] -> kw = 1,     dY[j]^T X'[j-1] -> kw = 0,     dY[j-1]^T X'[j] -> kw = 2        (iw = ow + kw - 1)
+// i.e. 10 block products per 8 staged blocks instead of 10 per 20, into three accumulators (independent MFMA chains); the blocks of step
+// s+2 are in flight in registers, those of step s+1 are written to the ring while step s multiplies: one barrier per step.
+// Work split: the (class, tile, row pair) triples in class-major order are M = 100 n_tiles "macro steps" of equal cost; workgroup q of Q
+// takes [M q / Q, M (q+1) / Q) and flushes its accumulators whenever the class changes.  The segment of slice q in class c goes to partial
+// slot q + c (both only grow along the order, so the slot is unique): part[(q + c) * 3 + kw][co][ci]; wgrad_rows4_reduce_k adds the
+// slots of a class in slice order.  Equal work for every workgroup whatever the batch size; no atomics, fixed order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rows4_nd(int k) { return k == 1 ? 4 : 3; }                 // valid output rows (or planes) of a tap offset
+__device__ __forceinline__ int rows4_class_rows(int c) { return rows4_nd(c / 3) * rows4_nd(c % 3); }
+__device__ __forceinline__ int rows4_class_start(int c)   // row pairs of the classes before c: 9, 12, 9, 12, 16, 12, 9, 12, 9
+{
+    int s = 0;
+    for (int i = 0; i < c; ++i) s += rows4_class_rows(i);
+    return s;
+}
+__device__ __forceinline__ int64_t rows4_slice_begin(int64_t M, int q, int Q) { return M * q / Q; }
+struct Rows4Iter {   // position in the class-major macro-step order, and the step inside the row pair
+    int c, tile, r, j, nc;
+    __device__ __forceinline__ void seek(int64_t m, int n_tiles)
+    {
+        c = 0;
+        while (c < 8 && (int64_t)rows4_class_start(c + 1) * n_tiles <= m) ++c;
+        nc = rows4_class_rows(c);
+        const int64_t rem = m - (int64_t)rows4_class_start(c) * n_tiles;
+        tile = (int)(rem / nc), r = (int)(rem % nc), j = 0;
+    }
+    __device__ __forceinline__ void next(int n_tiles)
+    {
+        if (++j < 4) return;
+        j = 0;
+        if (++r < nc) return;
+        r = 0;
+        if (++tile < n_tiles) return;
+        tile = 0, ++c, nc = rows4_class_rows(c < 9 ? c : 8);
+    }
+    __device__ __forceinline__ void positions(int& pi, int& po) const
+    {
+        const int kd = c / 3, kh = c % 3, nh = rows4_nd(kh), a = r / nh, b = r % nh;
+        const int od = (kd == 0) + a, oh = (kh == 0) + b;
+        po = od * 16 + oh * 4 + j;
+        pi = (od + kd - 1) * 16 + (oh + kh - 1) * 4 + j;
+    }
+};
+template <int CIN, int COUT, int INMODE, int GIN>
+__global__ __launch_bounds__((COUT / 32) * (CIN / 32) * 64) void wgrad_rows4_k(WgradArgs A)
+{
+    static_assert(CIN % 32 == 0 && COUT % 32 == 0, "32 x 32 output blocks");
+    constexpr int CB = COUT / 32, IB = CIN / 32, NT = CB * IB * 64;
+    constexpr int SDY = COUT + 4, SX = CIN + 4;   // [leaf][channel] blocks, see wgrad32_k
+    __shared__ __attribute__((aligned(16))) float sdy[3][32][SDY];
+    __shared__ __attribute__((aligned(16))) float sx[3][32][SX];
+    // XCD-aware slice number: workgroup b is observed to run on XCD b % 8 (speed only); every XCD gets a contiguous range of slices, i.e. of
+    // tiles of a class, so the ten row pairs that share a dY / X' row meet in one L2
+    int q;
+    const int Q = gridDim.x;
+    {
+        const int lin = blockIdx.x, xcd = lin & 7, qq = Q >> 3, r = Q & 7;
+        q = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (lin >> 3);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = wave / IB, ib = wave % IB;
+    const int64_t M = (int64_t)100 * A.n_tiles, m0 = rows4_slice_begin(M, q, Q), m1 = rows4_slice_begin(M, q + 1, Q);
+    const int total = (int)(m1 - m0) * 4;
+    constexpr int CPG = GIN > 0 ? CIN / GIN : 1;
+    constexpr int ND = ((COUT / 4) * 32 + NT - 1) / NT, NX = ((CIN / 4) * 32 + NT - 1) / NT;
+    f32x4 rdy[ND], rx[NX];
+    Rows4Iter itf, itw, itc;   // the step being fetched / written to the ring / multiplied
+    itf.seek(m0, A.n_tiles), itw = itf, itc = itf;
+    int nf = 0;
+    auto fetch = [&]() {
+        if (nf >= total) return;   // (uniform)
+        ++nf;
+        if ((WGRAD_ABL & 1) && nf > 1) {
+            itf.next(A.n_tiles);
+            return;
+        }
+        int pi, po;
+        itf.positions(pi, po);
+        const vq_buf dyb = buf_of((const f32x4*)A.dy + (size_t)itf.tile * 64 * (COUT / 4) * 32);
+        const vq_buf xb = buf_of((const f32x4*)A.x + (size_t)itf.tile * 64 * (CIN / 4) * 32);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int i = threadIdx.x + d * NT;
+            if (i < (COUT / 4) * 32) rdy[d] = buf_ld16(dyb, (unsigned)i * 16u, (unsigned)po * (COUT / 4) * 512u);
+        }
+#pragma unroll
+        for (int d = 0; d < NX; ++d) {
+            const int i = threadIdx.x + d * NT;
+            if (i < (CIN / 4) * 32) rx[d] = buf_ld16(xb, (unsigned)i * 16u, (unsigned)pi * (CIN / 4) * 512u);
+        }
+        itf.next(A.n_tiles);
+    };
+    float tia[NX][4], tib[NX][4];
+    int t_tile = -1;
+    auto load_transform = [&](int tile) {
+#pragma unroll
+        for (int dd = 0; dd < NX; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (CIN / 4) * 32) {
+                const int quad = i >> 5, leaf = i & 31;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = 4 * quad + kk;
+                    if (INMODE == 1) {
+                        const int g = ch / CPG;
+                        tia[dd][kk] = A.rstd[((size_t)tile * GIN + g) * 32 + leaf] * A.gamma[ch];
+                        tib[dd][kk] = __builtin_fmaf(-A.mean[((size_t)tile * GIN + g) * 32 + leaf], tia[dd][kk], A.beta[ch]);
+                    } else if (INMODE == 2) {
+                        tia[dd][kk] = A.gate[((size_t)tile * CIN + ch) * 32 + leaf];
+                    }
+                }
+            }
+        }
+    };
+    auto stage = [&](int slot) {
+        if (INMODE != 0 && itw.tile != t_tile) load_transform(itw.tile), t_tile = itw.tile;   // (uniform)
+        itw.next(A.n_tiles);
+        if (WGRAD_ABL & 4) return;
+#pragma unroll
+        for (int dd = 0; dd < ND; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (COUT / 4) * 32) *(f32x4*)&sdy[slot][i & 31][4 * (i >> 5)] = rdy[dd];
+        }
+#pragma unroll
+        for (int dd = 0; dd < NX; ++dd) {
+            const int i = threadIdx.x + dd * NT;
+            if (i < (CIN / 4) * 32) {
+                const int quad = i >> 5, leaf = i & 31;
+                const f32x4 v = rx[dd];
+                float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (INMODE == 1) o[kk] = fmaxf(__builtin_fmaf(o[kk], tia[dd][kk], tib[dd][kk]), 0.0f);
+                    else if (INMODE == 2) o[kk] = o[kk] * tia[dd][kk];
+                }
+                *(f32x4*)&sx[slot][leaf][4 * quad] = (f32x4){o[0], o[1], o[2], o[3]};
+            }
+        }
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    fetch();
+    if (total > 0) {
+        stage(0);
+        fetch();
+    }
+    __syncthreads();
+    int cur = 0, prev = 2;   // ring slots of step s and s-1
+    for (int s = 0; s < total; ++s) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        if (s + 1 < total) {   // (uniform)
+            stage(nxt);        // slot of step s-2: its last readers were the MFMAs of step s-1 (barrier below)
+            fetch();
+        }
+        const int rA = lane >> 5;
+        if (WGRAD_ABL & 2) {
+        } else if (itc.j == 0) {   // (uniform) first position of a row: the centre tap only
+#pragma unroll 4
+            for (int m = 0; m < 16; ++m) acc[1] = mfma32(sdy[cur][2 * m + rA][32 * cb + (lane & 31)], sx[cur][2 * m + rA][32 * ib + (lane & 31)], acc[1]);
+        } else {
+#pragma unroll 4
+            for (int m = 0; m < 16; ++m) {   // (four leaf pairs per trip: sixteen operand registers live, not sixty-four)
+                const float ac = sdy[cur][2 * m + rA][32 * cb + (lane & 31)], bc = sx[cur][2 * m + rA][32 * ib + (lane & 31)];
+                const float ap = sdy[prev][2 * m + rA][32 * cb + (lane & 31)], bp = sx[prev][2 * m + rA][32 * ib + (lane & 31)];
+                acc[1] = mfma32(ac, bc, acc[1]);
+                acc[0] = mfma32(ac, bp, acc[0]);
+                acc[2] = mfma32(ap, bc, acc[2]);
+            }
+        }
+        // end of the class segment (or of the slice): the three taps go to partial slot q + class
+        const int c_now = itc.c;
+        itc.next(A.n_tiles);
+        if (s + 1 == total || itc.c != c_now) {   // (uniform)
+            float* dst = A.part + (size_t)(q + c_now) * 3 * COUT * CIN;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = 32 * ib + (lane & 31);
+                    dst[((size_t)t * COUT + co) * CIN + ci] = acc[t][r];
+                    acc[t][r] = 0.0f;
+                }
+            }
+        }
+        prev = cur, cur = nxt;
+        if (!(WGRAD_ABL & 4)) __syncthreads();
+    }
+}
+// dW[(row0+co)*IC + ci][tap = 3 c + kw] = scale * sum over the slices q that meet class c (ascending) of part[(q + c) * 3 + kw][co][ci]
+__global__ __launch_bounds__(256) void wgrad_rows4_reduce_k(const float* __restrict__ part, int Q, int n_tiles, int COUT, int CIN, float* __restrict__ dW, int row0,
+                                                            int IC, float scale)
+{
+    const int64_t M = (int64_t)100 * n_tiles, total = (int64_t)27 * COUT * CIN;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ci = t % CIN, co = (t / CIN) % COUT, tap = (int)(t / ((int64_t)CIN * COUT)), c = tap / 3, kw = tap % 3;
+        const int64_t lo = (int64_t)rows4_class_start(c) * n_tiles, hi = (int64_t)rows4_class_start(c + 1) * n_tiles - 1;   // first / last macro step
+        int q0 = (int)(lo * Q / M), q1 = (int)(hi * Q / M);
+        while (q0 > 0 && rows4_slice_begin(M, q0, Q) > lo) --q0;
+        while (q0 + 1 < Q && rows4_slice_begin(M, q0 + 1, Q) <= lo) ++q0;
+        while (q1 > 0 && rows4_slice_begin(M, q1, Q) > hi) --q1;
+        while (q1 + 1 < Q && rows4_slice_begin(M, q1 + 1, Q) <= hi) ++q1;
+        float s = 0.0f;
+        for (int q = q0; q <= q1; ++q) {
+            if (rows4_slice_begin(M, q + 1, Q) == rows4_slice_begin(M, q, Q)) continue;   // empty slice (Q > M)
+            s += part[(((size_t)(q + c) * 3 + kw) * COUT + co) * CIN + ci];
+        }
+        dW[((size_t)(row0 + co) * IC + ci) * 27 + tap] = scale * s;
     }
 }
 

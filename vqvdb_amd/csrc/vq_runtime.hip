@@ -210,6 +210,7 @@ struct vqhip_codec {
     char* ft_part = nullptr;                                       // partial-gradient scratch
     size_t ft_part_bytes = 0;
     bool full_training = false, keep_y1 = false, weights_stale = false;
+    bool train_wgrad_rows = true;    // training backward: weight gradients of the k3 layers at 4^3 by wgrad_rows4_k (VQHIP_TRAIN_WGRAD=pairs: wgrad32_k)
     bool train_stem_lut = true;      // training forward: decoder stem through the (tap, code) table rebuilt every step (VQHIP_TRAIN_STEM=conv: the real conv)
     bool train_folded_tail = true;   // training step: up_conv + PixelShuffle3D + final as one folded operator (vq_train_tail.h); VQHIP_TRAIN_TAIL=unfolded keeps the layer-by-layer tail
     float* z4_out = nullptr;   // set around encode_chunk by the training forward: latent also in the L4 layout
@@ -1664,6 +1665,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD")) c->train_wgrad_rows = std::strcmp(e, "pairs") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "gather") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
