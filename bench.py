@@ -390,7 +390,11 @@ def main():
                     "frac_note": "whole_step_frac and by_class[*].frac count the FLOPs the step ISSUES on the matrix pipe (padding taps skipped, folded tail at its "
                                  "folded cost; forward + data gradients + weight gradients, TRAIN_ISSUED_FLOP in bench.py) over the measured time / 157.3 TFLOP/s: "
                                  "true utilisations, <= 1.  ratio_nominal_dense_* = 3 x the dense forward count of the reference ops over the same time: what the "
-                                 "algebraic eliminations buy, not a utilisation (it exceeds 1 at 8192 leaves per rank)"}
+                                 "algebraic eliminations buy, not a utilisation (it exceeds 1 at 8192 leaves per rank)",
+                    "streams": 1 if os.environ.get("VQHIP_TRAIN_STREAMS") == "1" else 2,
+                    "streams_note": "weight / bias gradients run on a second stream beside the data-gradient chain: by_class times are event spans on "
+                                    "either stream, they overlap, and kernel_time_ms_per_step exceeds ms_per_step; whole_step_frac (from the wall time) "
+                                    "is the utilisation of the step"}
             ksteps = max(2, min(args.steps, 6))
             for per_rank_b in (2048, 8192):
                 x = leaves[0][:per_rank_b]

@@ -210,6 +210,10 @@ struct vqhip_codec {
     char* ft_part = nullptr;                                       // partial-gradient scratch
     size_t ft_part_bytes = 0;
     bool full_training = false, keep_y1 = false, weights_stale = false;
+    bool train_side_stream = true;   // training backward: weight / bias gradients on a second stream beside the data-gradient chain (VQHIP_TRAIN_STREAMS=1: one stream)
+    hipStream_t ft_side = nullptr;
+    std::vector<hipEvent_t> ft_ev;   // fork / join events of the side stream, reused every step
+    size_t ft_ev_next = 0;
     bool train_wgrad_rows = true;    // training backward: weight gradients of the k3 layers at 4^3 by wgrad_rows4_k (VQHIP_TRAIN_WGRAD=pairs: wgrad32_k)
     bool train_stem_lut = true;      // training forward: decoder stem through the (tap, code) table rebuilt every step (VQHIP_TRAIN_STEM=conv: the real conv)
     bool train_folded_tail = true;   // training step: up_conv + PixelShuffle3D + final as one folded operator (vq_train_tail.h); VQHIP_TRAIN_TAIL=unfolded keeps the layer-by-layer tail
@@ -835,6 +839,12 @@ struct Launcher {
     template <typename F>
     void run(const char* name, F&& f)
     {
+        run_on(s, name, f);
+    }
+    // the same for launches that f() puts on another stream (profiling events go to that stream)
+    template <typename F>
+    void run_on(hipStream_t st, const char* name, F&& f)
+    {
         if (rc != VQHIP_OK) return;
         KernelTimer t;
         if (c->profiling) {
@@ -842,11 +852,11 @@ struct Launcher {
             t.leaves = leaves;
             hipEventCreate(&t.start);
             hipEventCreate(&t.stop);
-            hipEventRecord(t.start, s);
+            hipEventRecord(t.start, st);
         }
         f();
         if (c->profiling) {
-            hipEventRecord(t.stop, s);
+            hipEventRecord(t.stop, st);
             c->timers.push_back(t);
         }
         hipError_t e = hipGetLastError();
@@ -1666,6 +1676,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD")) c->train_wgrad_rows = std::strcmp(e, "pairs") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_STREAMS")) c->train_side_stream = std::strcmp(e, "1") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "gather") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1694,6 +1705,8 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->ft_V) hipFree(c->ft_V);
     if (c->ft_ws) hipFree(c->ft_ws);
     if (c->ft_part) hipFree(c->ft_part);
+    for (hipEvent_t e : c->ft_ev) hipEventDestroy(e);
+    if (c->ft_side) hipStreamDestroy(c->ft_side);
     if (c->tr_recon) hipFree(c->tr_recon);
     if (c->tr_loss_part) hipFree(c->tr_loss_part);
     for (int i = 0; i < 2; ++i) {
