@@ -514,42 +514,70 @@ __global__ __launch_bounds__(((COUT + 31) / 32) * ((CIN + 31) / 32) * 64) void w
 // part layout as wgrad32_k: part[((grp*n_chunks + chunk)*27 + tap)*256 + co*16 + ci].
 __global__ __launch_bounds__(192) void wgrad16_rows_k(WgradArgs A, int n_chunks)
 {
-    __shared__ float sdy[8][16][33];
-    __shared__ float sx[8][16][33];
+    // blocks as [position][leaf][16 channels]: a thread's float4 (4 channels of one leaf) is ONE 16-byte write, and the 64 operand reads of an
+    // MFMA (lane = (channel, leaf 4m + k)) cover 64 consecutive floats
+    __shared__ __attribute__((aligned(16))) float sdy[8][32][16];
+    __shared__ __attribute__((aligned(16))) float sx[8][32][16];
     const int kdkh = blockIdx.x, kd = kdkh / 3, kh = kdkh % 3, grp = blockIdx.y, chunk = blockIdx.z;
     const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6;   // three waves: one kw tap each, staging shared
     const int t0 = grp * A.tiles_per_group, t1 = min(A.n_tiles, t0 + A.tiles_per_group);
     const int r0 = chunk * 64 / n_chunks, r1 = (chunk + 1) * 64 / n_chunks;   // output rows (od*8 + oh) of this chunk
+    // staging: element i = tid + 192 k (k = 0..5, i < 1024) is float4 (position i >> 7, quad (i >> 5) & 3, leaf i & 31): the leaf of a thread
+    // never changes and its quad alternates between q0 and q0 ^ 2, so the GroupNorm scale / shift of its 8 channels are loaded once per tile
+    // (they used to be re-loaded for every element: 16 scalar loads per float4)
+    const int leaf = threadIdx.x & 31, q0 = (threadIdx.x >> 5) & 3;
+    float tia[2][4], tib[2][4];
+    f32x4 rdy[6], rx[6];
+    auto row_valid = [&](int row) { const int id = (row >> 3) + kd - 1, ih = (row & 7) + kh - 1; return id >= 0 && id <= 7 && ih >= 0 && ih <= 7; };
+    auto fetch = [&](int tile, int row) {   // the 8 dY blocks of output row `row` and the 8 X blocks of its input row -> registers
+        const int irow = ((row >> 3) + kd - 1) * 8 + (row & 7) + kh - 1;
+        const vq_buf dyb = buf_of((const f32x4*)A.dy + ((size_t)tile * 512 + row * 8) * 128);
+        const vq_buf xb = buf_of((const f32x4*)A.x + ((size_t)tile * 512 + irow * 8) * 128);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = threadIdx.x + 192 * k;
+            if (i < 1024) rdy[k] = buf_ld16(dyb, (unsigned)i * 16u, 0u), rx[k] = buf_ld16(xb, (unsigned)i * 16u, 0u);
+        }
+    };
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int tile = t0; tile < t1; ++tile) {
-        for (int row = r0; row < r1; ++row) {
-            const int id = (row >> 3) + kd - 1, ih = (row & 7) + kh - 1;
-            if (id < 0 || id > 7 || ih < 0 || ih > 7) continue;   // wave-uniform
-            __syncthreads();
-            for (int i = threadIdx.x; i < 8 * 4 * 32; i += 192) {   // 8 positions x 4 quads x 32 leaves, float4 each
-                const int leaf = i & 31, quad = (i >> 5) & 3, w = i >> 7;
-                const f32x4 v = ((const f32x4*)A.dy)[(((size_t)tile * 512 + row * 8 + w) * 4 + quad) * 32 + leaf];
-                float* d = &sdy[w][4 * quad][leaf];
-                d[0] = v.x, d[33] = v.y, d[66] = v.z, d[99] = v.w;
-                const f32x4 xv = ((const f32x4*)A.x)[(((size_t)tile * 512 + (id * 8 + ih) * 8 + w) * 4 + quad) * 32 + leaf];
-                float o[4] = {xv.x, xv.y, xv.z, xv.w};
+        int row = r0;
+        while (row < r1 && !row_valid(row)) ++row;
+        if (row >= r1) break;   // (the valid rows do not depend on the tile)
+        fetch(tile, row);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {   // X' = relu(GroupNorm(8,16)(X)) as the forward conv formed it
-                    const int ch = 4 * quad + k, gidx = ch >> 1;
-                    const float ia = A.rstd[((size_t)tile * 8 + gidx) * 32 + leaf] * A.gamma[ch];
-                    const float ib = __builtin_fmaf(-A.mean[((size_t)tile * 8 + gidx) * 32 + leaf], ia, A.beta[ch]);
-                    sx[w][ch][leaf] = fmaxf(__builtin_fmaf(o[k], ia, ib), 0.0f);
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // X' = relu(GroupNorm(8,16)(X)) as the forward conv formed it
+                const int ch = 4 * (q0 ^ (2 * h)) + k, gidx = ch >> 1;
+                tia[h][k] = A.rstd[((size_t)tile * 8 + gidx) * 32 + leaf] * A.gamma[ch];
+                tib[h][k] = __builtin_fmaf(-A.mean[((size_t)tile * 8 + gidx) * 32 + leaf], tia[h][k], A.beta[ch]);
+            }
+        while (row < r1) {
+            __syncthreads();   // the previous row's MFMAs have read the blocks
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = threadIdx.x + 192 * k;
+                if (i < 1024) {
+                    const int w = i >> 7, quad = (i >> 5) & 3, h = k & 1;   // quad = q0 ^ (2 h): 192 k / 32 = 6 k = 2 k (mod 4)
+                    *(f32x4*)&sdy[w][leaf][4 * quad] = rdy[k];
+                    const f32x4 v = rx[k];
+                    *(f32x4*)&sx[w][leaf][4 * quad] = (f32x4){fmaxf(__builtin_fmaf(v.x, tia[h][0], tib[h][0]), 0.0f), fmaxf(__builtin_fmaf(v.y, tia[h][1], tib[h][1]), 0.0f),
+                                                              fmaxf(__builtin_fmaf(v.z, tia[h][2], tib[h][2]), 0.0f), fmaxf(__builtin_fmaf(v.w, tia[h][3], tib[h][3]), 0.0f)};
                 }
             }
+            int nrow = row + 1;
+            while (nrow < r1 && !row_valid(nrow)) ++nrow;
+            if (nrow < r1) fetch(tile, nrow);   // in flight during this row's MFMAs
             __syncthreads();
 #pragma unroll
             for (int ow = 0; ow < 8; ++ow) {
                 const int iw = ow + kw - 1;
                 if (iw < 0 || iw > 7) continue;   // wave-uniform
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    acc = mfma16(sdy[ow][lane & 15][4 * m + (lane >> 4)], sx[iw][lane & 15][4 * m + (lane >> 4)], acc);
+                for (int m = 0; m < 8; ++m) acc = mfma16(sdy[ow][4 * m + (lane >> 4)][lane & 15], sx[iw][4 * m + (lane >> 4)][lane & 15], acc);
             }
+            row = nrow;
         }
     }
     float* dst = A.part + (((size_t)grp * n_chunks + chunk) * 27 + kdkh * 3 + kw) * 256;
