@@ -55,7 +55,7 @@ static void run(const char* name, int nt, int ng, int chunks, WgradArgs A)
 template <int CIN, int COUT>
 static void run_rows(const char* name, int nt, int Q, WgradArgs A)
 {
-    constexpr int NT = (COUT / 32) * (CIN / 32) * 64;
+    constexpr int NT = rows4_threads<CIN, COUT>();
     A.n_tiles = nt, A.KT = 27;
     auto k = wgrad_rows4_k<CIN, COUT, 0, 0>;
     hipEvent_t a, b;
@@ -96,7 +96,7 @@ int main()
 #if 1
         for (int Q : {256, 512, 768}) run_rows<128, 64>("stem 128->64", nt, Q, A);
         for (int Q : {256, 512, 768, 1024}) run_rows<64, 64>("res64 64->64", nt, Q, A);
-        for (int Q : {512, 1024}) run_rows<32, 32>("res32 32->32", nt, Q, A);
+        for (int Q : {256, 512, 1024}) run_rows<32, 32>("res32 32->32", nt, Q, A);
 #endif
     }
     return 0;

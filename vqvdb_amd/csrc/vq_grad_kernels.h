@@ -585,16 +585,29 @@ __global__ __launch_bounds__(192) void wgrad16_rows_k(WgradArgs A, int n_chunks)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = v[r];
 }
-// dW[(row0+co)*IC + ci][tap] = scale * sum_grp part[grp][tap][co][ci]
+// dW[(row0+co)*IC + ci][tap] = scale * sum_grp part[grp][tap][co][ci].  A workgroup takes 64 consecutive outputs; wave w adds the groups
+// w, w+4, w+8, ... (ascending, several loads in flight), the four wave sums are added in wave order: a fixed order, and a quarter of the
+// dependent-load chain of one thread per output (that kernel took 60-120 us per layer for 7-30 MB of partials).
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ part, int n_groups, int KT, int COUT, int CIN, float* __restrict__ dW, int row0,
                                                       int IC, float scale)
 {
+    __shared__ float red[4][64];
     const int64_t total = (int64_t)KT * COUT * CIN;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int ci = t % CIN, co = (t / CIN) % COUT, tap = (int)(t / ((int64_t)CIN * COUT));
+    const int o = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {   // (uniform trip count)
+        const int64_t t = base + o;
         float s = 0.0f;
-        for (int g = 0; g < n_groups; ++g) s += part[(((size_t)g * KT + tap) * COUT + co) * CIN + ci];
-        dW[((size_t)(row0 + co) * IC + ci) * KT + tap] = scale * s;
+        if (t < total) {
+#pragma unroll 4
+            for (int g = w; g < n_groups; g += 4) s += part[(size_t)g * total + t];
+        }
+        red[w][o] = s;
+        __syncthreads();
+        if (w == 0 && t < total) {
+            const int ci = t % CIN, co = (t / CIN) % COUT, tap = (int)(t / ((int64_t)CIN * COUT));
+            dW[((size_t)(row0 + co) * IC + ci) * KT + tap] = scale * (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
+        }
+        __syncthreads();
     }
 }
 
@@ -648,12 +661,19 @@ struct Rows4Iter {   // position in the class-major macro-step order, and the st
         pi = (od + kd - 1) * 16 + (oh + kh - 1) * 4 + j;
     }
 };
+// A 32 x 32 output (the encoder's residual block) would be ONE wave doing the staging and the MFMAs in turn; it is cut into four 16 x 16
+// quadrants on the 16x16x4 MFMA instead (Q16): four waves share the staged blocks, same flops per wave-cycle.
+template <int CIN, int COUT>
+constexpr int rows4_threads() { return CIN == 32 && COUT == 32 ? 256 : (COUT / 32) * (CIN / 32) * 64; }
 template <int CIN, int COUT, int INMODE, int GIN>
-__global__ __launch_bounds__((COUT / 32) * (CIN / 32) * 64) void wgrad_rows4_k(WgradArgs A)
+__global__ __launch_bounds__((rows4_threads<CIN, COUT>())) void wgrad_rows4_k(WgradArgs A)
 {
     static_assert(CIN % 32 == 0 && COUT % 32 == 0, "32 x 32 output blocks");
-    constexpr int CB = COUT / 32, IB = CIN / 32, NT = CB * IB * 64;
-    constexpr int SDY = COUT + 4, SX = CIN + 4;   // [leaf][channel] blocks, see wgrad32_k
+    constexpr bool Q16 = CIN == 32 && COUT == 32;
+    constexpr int CB = Q16 ? 2 : COUT / 32, IB = Q16 ? 2 : CIN / 32, NT = CB * IB * 64;
+    // [leaf][channel] blocks, see wgrad32_k.  Q16: row stride 48 floats — the 64 operand reads of a 16x16x4 MFMA (16 channels x 4 leaves) then
+    // fall on every bank exactly twice
+    constexpr int SDY = Q16 ? 48 : COUT + 4, SX = Q16 ? 48 : CIN + 4;
     __shared__ __attribute__((aligned(16))) float sdy[3][32][SDY];
     __shared__ __attribute__((aligned(16))) float sx[3][32][SX];
     // XCD-aware slice number: workgroup b is observed to run on XCD b % 8 (speed only); every XCD gets a contiguous range of slices, i.e. of
@@ -744,10 +764,13 @@ __global__ __launch_bounds__((COUT / 32) * (CIN / 32) * 64) void wgrad_rows4_k(W
         }
     };
     f32x16 acc[3];
+    f32x4 acc4[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        acc4[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
     fetch();
     if (total > 0) {
         stage(0);
@@ -763,6 +786,21 @@ __global__ __launch_bounds__((COUT / 32) * (CIN / 32) * 64) void wgrad_rows4_k(W
         }
         const int rA = lane >> 5;
         if (WGRAD_ABL & 2) {
+        } else if (Q16) {
+            const int lk = lane >> 4, lc = lane & 15;
+            if (itc.j == 0) {   // (uniform)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc4[1] = mfma16(sdy[cur][4 * m + lk][16 * cb + lc], sx[cur][4 * m + lk][16 * ib + lc], acc4[1]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float ac = sdy[cur][4 * m + lk][16 * cb + lc], bc = sx[cur][4 * m + lk][16 * ib + lc];
+                    const float ap = sdy[prev][4 * m + lk][16 * cb + lc], bp = sx[prev][4 * m + lk][16 * ib + lc];
+                    acc4[1] = mfma16(ac, bc, acc4[1]);
+                    acc4[0] = mfma16(ac, bp, acc4[0]);
+                    acc4[2] = mfma16(ap, bc, acc4[2]);
+                }
+            }
         } else if (itc.j == 0) {   // (uniform) first position of a row: the centre tap only
 #pragma unroll 4
             for (int m = 0; m < 16; ++m) acc[1] = mfma32(sdy[cur][2 * m + rA][32 * cb + (lane & 31)], sx[cur][2 * m + rA][32 * ib + (lane & 31)], acc[1]);
@@ -783,6 +821,12 @@ __global__ __launch_bounds__((COUT / 32) * (CIN / 32) * 64) void wgrad_rows4_k(W
             float* dst = A.part + (size_t)(q + c_now) * 3 * COUT * CIN;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
+                if (Q16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((size_t)t * COUT + 16 * cb + 4 * (lane >> 4) + r) * CIN + 16 * ib + (lane & 15)] = acc4[t][r];
+                    acc4[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = 32 * ib + (lane & 31);
@@ -795,12 +839,16 @@ __global__ __launch_bounds__((COUT / 32) * (CIN / 32) * 64) void wgrad_rows4_k(W
         if (!(WGRAD_ABL & 4)) __syncthreads();
     }
 }
-// dW[(row0+co)*IC + ci][tap = 3 c + kw] = scale * sum over the slices q that meet class c (ascending) of part[(q + c) * 3 + kw][co][ci]
+// dW[(row0+co)*IC + ci][tap = 3 c + kw] = scale * sum over the slices q that meet class c of part[(q + c) * 3 + kw][co][ci]; the order of
+// wgrad_reduce_k: 64 outputs per workgroup, wave w adds the slices q0 + w, q0 + w + 4, ... ascending, then the four wave sums in wave order
 __global__ __launch_bounds__(256) void wgrad_rows4_reduce_k(const float* __restrict__ part, int Q, int n_tiles, int COUT, int CIN, float* __restrict__ dW, int row0,
                                                             int IC, float scale)
 {
+    __shared__ float red[4][64];
     const int64_t M = (int64_t)100 * n_tiles, total = (int64_t)27 * COUT * CIN;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int o = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {   // (COUT * CIN is a multiple of 64: one tap per trip)
+        const int64_t t = base + o;
         const int ci = t % CIN, co = (t / CIN) % COUT, tap = (int)(t / ((int64_t)CIN * COUT)), c = tap / 3, kw = tap % 3;
         const int64_t lo = (int64_t)rows4_class_start(c) * n_tiles, hi = (int64_t)rows4_class_start(c + 1) * n_tiles - 1;   // first / last macro step
         int q0 = (int)(lo * Q / M), q1 = (int)(hi * Q / M);
@@ -809,11 +857,18 @@ __global__ __launch_bounds__(256) void wgrad_rows4_reduce_k(const float* __restr
         while (q1 > 0 && rows4_slice_begin(M, q1, Q) > hi) --q1;
         while (q1 + 1 < Q && rows4_slice_begin(M, q1 + 1, Q) <= hi) ++q1;
         float s = 0.0f;
-        for (int q = q0; q <= q1; ++q) {
-            if (rows4_slice_begin(M, q + 1, Q) == rows4_slice_begin(M, q, Q)) continue;   // empty slice (Q > M)
-            s += part[(((size_t)(q + c) * 3 + kw) * COUT + co) * CIN + ci];
+        const float* p = part + ((size_t)kw * COUT + co) * CIN + ci;
+#pragma unroll 4
+        for (int q = q0 + w; q <= q1; q += 4) {
+            // (an empty slice, Q > M, wrote nothing: its slot may hold anything)
+            const bool live = rows4_slice_begin(M, q + 1, Q) != rows4_slice_begin(M, q, Q);
+            const float v = p[(size_t)(q + c) * 3 * COUT * CIN];
+            s += live ? v : 0.0f;
         }
-        dW[((size_t)(row0 + co) * IC + ci) * 27 + tap] = scale * s;
+        red[w][o] = s;
+        __syncthreads();
+        if (w == 0) dW[((size_t)(row0 + co) * IC + ci) * 27 + tap] = scale * (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
+        __syncthreads();
     }
 }
 
