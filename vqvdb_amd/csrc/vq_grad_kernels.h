@@ -288,14 +288,20 @@ __global__ __launch_bounds__(512) void final_wgrad_k(const float* __restrict__ d
         if (lane == 0) part[864] = bsum;
     }
 }
-// dst[i] = scale * sum over parts (ascending) of part[p][i]
+// dst[i] = scale * sum over the parts of part[p][i].  64 outputs per workgroup (grid = ceil(n / 64)); wave w adds the parts w, w+4, ...
+// ascending, the four wave sums are added in wave order (wgrad_reduce_k's scheme).
 __global__ __launch_bounds__(256) void parts_reduce_k(const float* __restrict__ part, int n_parts, int n, float* __restrict__ dst, float scale)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + o;
     float s = 0.0f;
-    for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + i];
-    dst[i] = scale * s;
+    if (i < n) {
+#pragma unroll 4
+        for (int p = w; p < n_parts; p += 4) s += part[(size_t)p * n + i];
+    }
+    red[w][o] = s;
+    __syncthreads();
+    if (w == 0 && i < n) dst[i] = scale * (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
 }
 // dst[c] = scale * sum over tiles and leaves of part[tile][c][32]  (bias / GroupNorm-affine gradients from per-(tile,channel,leaf) sums).
 // One 256-thread block per channel: thread t walks tiles t>>5, t>>5 + 8, ... for leaf t&31, then a fixed LDS tree (deterministic).
@@ -1150,11 +1156,13 @@ __global__ __launch_bounds__(256) void deconv_down_k(const float* __restrict__ d
     }
 }
 
-// weight gradient of the first conv (1 -> 16, k3 p1 @8^3): part[tile][16*27] ([co*27 + tap]); 9 waves = (kd, kh), 3 kw each
+// weight gradient of the first conv (1 -> 16, k3 p1 @8^3): part[tile * 8 + od][16*27] ([co*27 + tap]); grid (tiles, 8 output planes);
+// 9 waves = (kd, kh), 3 kw each; lane = (leaf, half of the plane's 64 positions).  (One workgroup per tile walked all 512 positions: 64
+// workgroups at 2048 leaves, a quarter of the CUs, 0.18 ms for 67 MB of dY.)
 __global__ __launch_bounds__(576) void wgrad_first_k(const float* __restrict__ dy /*L4 16ch@8^3*/, const float* __restrict__ xt /*[tile][512][32]*/,
                                                      float* __restrict__ part)
 {
-    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, D = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const int kd = wave / 3, kh = wave % 3;
     float acc[3][16];
 #pragma unroll
@@ -1163,24 +1171,28 @@ __global__ __launch_bounds__(576) void wgrad_first_k(const float* __restrict__ d
         for (int c = 0; c < 16; ++c) acc[k][c] = 0.0f;
     const f32x4* dy4 = (const f32x4*)dy + (size_t)tile * 512 * 4 * 32 + j;
     const float* x = xt + (size_t)tile * 512 * 32 + j;
-    for (int P = 256 * h; P < 256 * h + 256; ++P) {
-        const int D = P >> 6, H = (P >> 3) & 7, Wd = P & 7;
-        const int d = D + kd - 1, hh = H + kh - 1;
-        if (d < 0 || d > 7 || hh < 0 || hh > 7) continue;
-        f32x4 g[4];
+    const int d = D + kd - 1;
+    if (d >= 0 && d <= 7) {   // (wave-uniform)
+#pragma unroll 2
+        for (int P = 64 * D + 32 * h; P < 64 * D + 32 * h + 32; ++P) {
+            const int H = (P >> 3) & 7, Wd = P & 7;
+            const int hh = H + kh - 1;
+            if (hh < 0 || hh > 7) continue;
+            f32x4 g[4];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) g[qd] = dy4[((size_t)P * 4 + qd) * 32];
+            for (int qd = 0; qd < 4; ++qd) g[qd] = dy4[((size_t)P * 4 + qd) * 32];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int xw = Wd + kw - 1;
-            if (xw < 0 || xw > 7) continue;
-            const float xv = x[(size_t)((d * 8 + hh) * 8 + xw) * 32];
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xw = Wd + kw - 1;
+                if (xw < 0 || xw > 7) continue;
+                const float xv = x[(size_t)((d * 8 + hh) * 8 + xw) * 32];
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                acc[kw][4 * qd + 0] = __builtin_fmaf(g[qd].x, xv, acc[kw][4 * qd + 0]);
-                acc[kw][4 * qd + 1] = __builtin_fmaf(g[qd].y, xv, acc[kw][4 * qd + 1]);
-                acc[kw][4 * qd + 2] = __builtin_fmaf(g[qd].z, xv, acc[kw][4 * qd + 2]);
-                acc[kw][4 * qd + 3] = __builtin_fmaf(g[qd].w, xv, acc[kw][4 * qd + 3]);
+                for (int qd = 0; qd < 4; ++qd) {
+                    acc[kw][4 * qd + 0] = __builtin_fmaf(g[qd].x, xv, acc[kw][4 * qd + 0]);
+                    acc[kw][4 * qd + 1] = __builtin_fmaf(g[qd].y, xv, acc[kw][4 * qd + 1]);
+                    acc[kw][4 * qd + 2] = __builtin_fmaf(g[qd].z, xv, acc[kw][4 * qd + 2]);
+                    acc[kw][4 * qd + 3] = __builtin_fmaf(g[qd].w, xv, acc[kw][4 * qd + 3]);
+                }
             }
         }
     }
@@ -1190,7 +1202,7 @@ __global__ __launch_bounds__(576) void wgrad_first_k(const float* __restrict__ d
         for (int c = 0; c < 16; ++c) {
             float v = acc[kw][c];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) part[(size_t)tile * 432 + c * 27 + (kd * 3 + kh) * 3 + kw] = v;
+            if (lane == 0) part[((size_t)tile * 8 + D) * 432 + c * 27 + (kd * 3 + kh) * 3 + kw] = v;
         }
 }
 
