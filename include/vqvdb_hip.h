@@ -223,6 +223,10 @@ int64_t vqhip_fulltrain_param_count(const vqhip_codec* codec);
 int vqhip_fulltrain_set_folded_tail(vqhip_codec* codec, int on);
 /* Training-mode forward only (test hook): every activation stays in the workspaces for vqhip_debug_fetch. */
 int vqhip_fulltrain_forward_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, void* hip_stream);
+/* Forward + backward of this rank's batch, enqueued on hip_stream (NULL: the codec's own).  Internally the weight / bias gradients,
+ * the codebook statistics and the fold of the decoder tail run on a second stream of the codec beside the data-gradient chain; the
+ * call returns with hip_stream made to wait for that stream, so work enqueued on hip_stream afterwards sees grads_dev / aux_dev
+ * complete, exactly as with one stream (environment VQHIP_TRAIN_STREAMS=1 keeps everything on hip_stream; same bits either way). */
 int vqhip_fulltrain_fwdbwd_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, int64_t n_global_leaves, float* grads_dev,
                                   float* aux_dev /* VQHIP_FULLTRAIN_AUX_FLOATS or NULL */, void* hip_stream);
 /* The same, with a hook between the two halves of the backward pass: decoder_done(user) runs on the calling thread right after the

@@ -836,6 +836,7 @@ struct Launcher {
     hipStream_t s;
     int64_t leaves;
     int rc = VQHIP_OK;
+    int64_t on_main = 0;   // launch groups put on s so far (Bwd::fork skips the event when nothing new has been enqueued)
     template <typename F>
     void run(const char* name, F&& f)
     {
@@ -846,6 +847,7 @@ struct Launcher {
     void run_on(hipStream_t st, const char* name, F&& f)
     {
         if (rc != VQHIP_OK) return;
+        if (st == s) ++on_main;
         KernelTimer t;
         if (c->profiling) {
             t.name = name;
