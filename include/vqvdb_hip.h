@@ -232,11 +232,14 @@ int vqhip_fulltrain_fwdbwd_device(vqhip_codec* codec, const float* leaves_dev, i
 /* The same, with a hook between the two halves of the backward pass: decoder_done(user) runs on the calling thread right after the
  * decoder's backward kernels have been enqueued (nothing is synchronised; non-zero return aborts).  From that point of the stream on,
  * grads_dev[vqhip_fulltrain_decoder_offset() ..] is final: a data-parallel caller records an event and all-reduces that slice on
- * another stream while the encoder half of the backward pass runs (vqvdb_amd/full_training.py). */
+ * another stream while the encoder half of the backward pass runs (vqvdb_amd/full_training.py).  WHICH stream to record that event on:
+ * vqhip_fulltrain_ready_stream() — the codec's second stream when the weight gradients run there (it has been ordered after the
+ * decoder's kernels on hip_stream at that point, without making hip_stream wait for it), NULL = hip_stream itself. */
 typedef int (*vqhip_phase_fn)(void* user);
 int vqhip_fulltrain_fwdbwd_overlap_device(vqhip_codec* codec, const float* leaves_dev, int64_t n_leaves, int64_t n_global_leaves, float* grads_dev,
                                           float* aux_dev, void* hip_stream, vqhip_phase_fn decoder_done, void* user);
 int64_t vqhip_fulltrain_decoder_offset(const vqhip_codec* codec);
+void* vqhip_fulltrain_ready_stream(const vqhip_codec* codec);
 /* step counts from 1 (bias correction).  Reference hyper-parameters: lr 1e-4 (cosine schedule on the host), betas 0.9 / 0.999,
  * eps 1e-8, weight_decay 1e-4 (training.py:104-108); EMA decay 0.95, eps 1e-4.  aux_dev NULL leaves the codebook untouched. */
 int vqhip_fulltrain_apply_device(vqhip_codec* codec, const float* grads_dev, const float* aux_dev, float lr, int64_t step, float beta1, float beta2,

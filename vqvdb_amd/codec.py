@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "vqhip_train_commit", "vqhip_set_small_batch_tiles", "vqhip_train_eval_device",
     "vqhip_fulltrain_begin", "vqhip_fulltrain_param_count", "vqhip_fulltrain_forward_device", "vqhip_fulltrain_fwdbwd_device",
     "vqhip_fulltrain_apply_device", "vqhip_fulltrain_get_params", "vqhip_fulltrain_set_params",
-    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info", "vqhip_fulltrain_fwdbwd_overlap_device", "vqhip_fulltrain_decoder_offset", "vqhip_fulltrain_set_folded_tail",
+    "vqhip_fulltrain_get_opt_state", "vqhip_fulltrain_set_opt_state", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_multi_worker_info", "vqhip_fulltrain_fwdbwd_overlap_device", "vqhip_fulltrain_decoder_offset", "vqhip_fulltrain_ready_stream", "vqhip_fulltrain_set_folded_tail",
 ]
 
 class _GridInfo(ctypes.Structure):
@@ -169,6 +169,8 @@ def load_library() -> ctypes.CDLL:
     lib.vqhip_fulltrain_set_folded_tail.argtypes = [vp, ci]
     lib.vqhip_fulltrain_decoder_offset.argtypes = [vp]
     lib.vqhip_fulltrain_decoder_offset.restype = ctypes.c_int64
+    lib.vqhip_fulltrain_ready_stream.argtypes = [vp]
+    lib.vqhip_fulltrain_ready_stream.restype = ctypes.c_void_p
     lib.vqhip_workspace_bytes.argtypes = [vp]
     lib.vqhip_workspace_bytes.restype = ctypes.c_int64
     lib.vqhip_chunk_leaves.argtypes = [vp]
@@ -194,7 +196,8 @@ def load_library() -> ctypes.CDLL:
         if getattr(lib, name).argtypes is None and name not in ("vqhip_version",):
             raise RuntimeError(f"codec.py: no argtypes declared for {name} (pointers would be truncated to 32 bits)")
         if name not in ("vqhip_destroy", "vqhip_last_error", "vqhip_version", "vqhip_multi_destroy", "vqhip_multi_last_error",
-                        "vqhip_fulltrain_param_count", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_fulltrain_decoder_offset"):
+                        "vqhip_fulltrain_param_count", "vqhip_workspace_bytes", "vqhip_chunk_leaves", "vqhip_fulltrain_decoder_offset",
+                        "vqhip_fulltrain_ready_stream"):
             getattr(lib, name).restype = ci
     _lib = lib
     return lib
@@ -427,6 +430,10 @@ class HipCodec:
 
     def fulltrain_decoder_offset(self) -> int:
         return int(self._lib.vqhip_fulltrain_decoder_offset(self._h))
+
+    def fulltrain_ready_stream(self) -> int:
+        """Raw HIP stream on which the decoder's gradients are complete at the decoder_done callback (0: the stream of the call)."""
+        return int(self._lib.vqhip_fulltrain_ready_stream(self._h) or 0)
 
     def fulltrain_apply_device(self, grads_ptr: int, aux_ptr: int, lr: float, step: int, betas=(0.9, 0.999), adam_eps: float = 1e-8,
                                weight_decay: float = 1e-4, ema_decay: float = 0.95, ema_eps: float = 1e-4, stream: int = 0):

@@ -88,7 +88,8 @@ class FullTrainer:
 
                 def decoder_done():
                     ev = torch.cuda.Event()
-                    ev.record(self.stream)
+                    ready = self.codec.fulltrain_ready_stream()   # the codec's second stream carries the weight gradients
+                    ev.record(torch.cuda.ExternalStream(ready, device=self.device) if ready else self.stream)
                     self.comm_stream.wait_event(ev)
                     with torch.cuda.stream(self.comm_stream):
                         pending.append(dist.all_reduce(self.grads[dec:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
