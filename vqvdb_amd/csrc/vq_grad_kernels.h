@@ -591,6 +591,135 @@ __global__ __launch_bounds__(192) void wgrad16_rows_k(WgradArgs A, int n_chunks)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = v[r];
 }
+// Weight gradient of the 16 -> 16, k3 p1 layers at 8^3, a plane at a time (round 3).  wgrad16_rows_k above re-reads every dY row and every X'
+// row once per (kd, kh) class: 9 x 0.77 x 134 MB = 930 MB at 2048 leaves, which is what its 0.17 ms are.  Here a workgroup keeps kd fixed and
+// walks the output rows oh = 0..7 of a plane (tile, od): the dY row goes to LDS, the input rows ih = oh-1, oh, oh+1 of plane id = od+kd-1
+// live in a ring of three row slots (each row is staged once per plane and serves three output rows; row oh+1 replaces row oh-2), so all nine (kh, kw) taps are fed
+// from 32 KB per output row instead of 96.  Eight waves = the eight output positions ow of the row: wave ow reads its dY block's operands
+// once and multiplies them with up to nine X' blocks (ih, iw = ow+kw-1); its nine partial accumulators are added over the waves in wave
+// order through LDS at the end of the workgroup.  grid (ceil(8 n_tiles / P), 3 = kd), P planes per workgroup; the rows of the next step
+// (dY row oh+1, X' row oh+2; three rows when a new plane starts) are in flight in registers during the MFMAs.
+// part[(kd * gridDim.x + block) * 9 + kh * 3 + kw][co * 16 + ci]; wgrad16_planes_reduce_k adds the workgroups of a kd in order.
+__global__ __launch_bounds__(512) void wgrad16_planes_k(WgradArgs A, int P)
+{
+    __shared__ __attribute__((aligned(16))) float sdy[8][32][16];
+    __shared__ __attribute__((aligned(16))) float sxr[3][8][32][16];
+    const int kd = blockIdx.y, n_od = kd == 1 ? 8 : 7, od0 = kd == 0 ? 1 : 0;
+    const int n_planes = n_od * A.n_tiles, p0 = blockIdx.x * P, p1 = min(p0 + P, n_planes);
+    float* dst = A.part + (size_t)(kd * gridDim.x + blockIdx.x) * 9 * 256;
+    if (p0 >= n_planes) return;   // (never read by the reduction)
+    const int lane = threadIdx.x & 63, ow = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lc = lane & 15, lk = lane >> 4;
+    // staging: thread -> float4 (position w0 and w0 + 4, quad, leaf) of a row: quad and leaf never change, so the GroupNorm scale / shift of
+    // its four channels are loaded once per tile
+    const int leaf = threadIdx.x & 31, quad = (threadIdx.x >> 5) & 3, w0 = threadIdx.x >> 7;
+    float tia[4], tib[4];
+    int t_tile = -1;
+    f32x4 rdy[2], rxa[2], rxb[2];
+    const int total = (p1 - p0) * 8;
+    auto where = [&](int s, int& tile, int& od, int& oh) {
+        const int p = p0 + (s >> 3);
+        tile = p / n_od, od = od0 + p % n_od, oh = s & 7;
+    };
+    auto fetch = [&](int s) {
+        if (s >= total) return;   // (uniform)
+        int tile, od, oh;
+        where(s, tile, od, oh);
+        const int id = od + kd - 1;
+        const vq_buf dyb = buf_of((const f32x4*)A.dy + ((size_t)tile * 512 + (od * 8 + oh) * 8) * 128);
+        const unsigned lo = (unsigned)(w0 * 128 + quad * 32 + leaf) * 16u;
+        rdy[0] = buf_ld16(dyb, lo, 0u), rdy[1] = buf_ld16(dyb, lo, 4u * 128u * 16u);
+        if (oh < 7) {   // (uniform) input row oh + 1
+            const vq_buf xb = buf_of((const f32x4*)A.x + ((size_t)tile * 512 + (id * 8 + oh + 1) * 8) * 128);
+            rxa[0] = buf_ld16(xb, lo, 0u), rxa[1] = buf_ld16(xb, lo, 4u * 128u * 16u);
+        }
+        if (oh == 0) {  // (uniform) a new plane: its input row 0 as well
+            const vq_buf xb = buf_of((const f32x4*)A.x + ((size_t)tile * 512 + (id * 8) * 8) * 128);
+            rxb[0] = buf_ld16(xb, lo, 0u), rxb[1] = buf_ld16(xb, lo, 4u * 128u * 16u);
+        }
+    };
+    auto xform = [&](f32x4 v) {   // X' = relu(GroupNorm(8,16)(X)) as the forward conv formed it
+        return (f32x4){fmaxf(__builtin_fmaf(v.x, tia[0], tib[0]), 0.0f), fmaxf(__builtin_fmaf(v.y, tia[1], tib[1]), 0.0f),
+                       fmaxf(__builtin_fmaf(v.z, tia[2], tib[2]), 0.0f), fmaxf(__builtin_fmaf(v.w, tia[3], tib[3]), 0.0f)};
+    };
+    auto stage = [&](int s) {
+        int tile, od, oh;
+        where(s, tile, od, oh);
+        if (tile != t_tile) {   // (uniform)
+            t_tile = tile;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = 4 * quad + k, g = ch >> 1;
+                tia[k] = A.rstd[((size_t)tile * 8 + g) * 32 + leaf] * A.gamma[ch];
+                tib[k] = __builtin_fmaf(-A.mean[((size_t)tile * 8 + g) * 32 + leaf], tia[k], A.beta[ch]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int w = w0 + 4 * h;
+            *(f32x4*)&sdy[w][leaf][4 * quad] = rdy[h];
+            if (oh < 7) *(f32x4*)&sxr[(oh + 1) % 3][w][leaf][4 * quad] = xform(rxa[h]);
+            if (oh == 0) *(f32x4*)&sxr[0][w][leaf][4 * quad] = xform(rxb[h]);
+        }
+    };
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    fetch(0);
+    for (int s = 0; s < total; ++s) {
+        __syncthreads();   // the previous step's MFMAs have read the row buffers
+        stage(s);
+        fetch(s + 1);      // in flight during this step's MFMAs
+        __syncthreads();
+        const int oh = s & 7;
+        float a[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m] = sdy[ow][4 * m + lk][lc];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh + kh - 1;
+            if (ih < 0 || ih > 7) continue;   // (uniform)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow + kw - 1;
+                if (iw < 0 || iw > 7) continue;   // (wave-uniform)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[kh * 3 + kw] = mfma16(a[m], sxr[ih % 3][iw][4 * m + lk][lc], acc[kh * 3 + kw]);
+            }
+        }
+    }
+    // the nine taps of the eight waves, added in wave order (scratch = the dY row buffer and the first ring slot: 9 x 256 floats)
+    float* red = &sdy[0][0][0];
+    static_assert(sizeof(sdy) >= 9 * 256 * sizeof(float), "reduction scratch");
+    for (int wv = 0; wv < 8; ++wv) {
+        __syncthreads();
+        if (ow == wv) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* q = red + t * 256 + (4 * lk + r) * 16 + lc;
+                    *q = wv == 0 ? acc[t][r] : *q + acc[t][r];
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 256; i += 512) dst[i] = red[i];
+}
+// dW[co][ci][tap = (kd*3+kh)*3+kw] = scale * sum over the workgroups of kd (ascending) of part[(kd * gx + b) * 9 + kh*3+kw][co*16+ci];
+// 64 outputs per workgroup, four waves each adding every fourth partial, wave sums in wave order (wgrad_reduce_k's scheme)
+__global__ __launch_bounds__(256) void wgrad16_planes_reduce_k(const float* __restrict__ part, int gx, int n_tiles, int P, float* __restrict__ dW, float scale)
+{
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * 64 + o;   // t < 27 * 256
+    const int tap = t >> 8, e = t & 255, kd = tap / 9, nb = ((kd == 1 ? 8 : 7) * n_tiles + P - 1) / P;
+    float s = 0.0f;
+#pragma unroll 4
+    for (int b = w; b < nb; b += 4) s += part[((size_t)(kd * gx + b) * 9 + tap % 9) * 256 + e];
+    red[w][o] = s;
+    __syncthreads();
+    if (w == 0) dW[(size_t)e * 27 + tap] = scale * (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
+}
+
 // dW[(row0+co)*IC + ci][tap] = scale * sum_grp part[grp][tap][co][ci].  A workgroup takes 64 consecutive outputs; wave w adds the groups
 // w, w+4, w+8, ... (ascending, several loads in flight), the four wave sums are added in wave order: a fixed order, and a quarter of the
 // dependent-load chain of one thread per output (that kernel took 60-120 us per layer for 7-30 MB of partials).
