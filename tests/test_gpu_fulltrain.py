@@ -132,6 +132,32 @@ def test_side_stream_gives_the_single_stream_gradients_bit_for_bit(weights, monk
         assert np.array_equal(one[0].view(np.uint32), one[2].view(np.uint32))
 
 
+def test_weight_gradient_kernel_families_agree(weights, monkeypatch):
+    """Round 3 replaced the pair-per-step weight-gradient kernels of the 4^3 k3 layers and of the 16-channel layers by the rolling-window
+    / plane-walking ones (wgrad_rows4_k in equal slices of the (class, tile, row pair) order, wgrad16_planes_k); VQHIP_TRAIN_WGRAD=pairs
+    keeps the old family.  Same sums in another order: every parameter gradient must agree to 2e-5 of its tensor's maximum — at batch
+    sizes that make the slicing awkward (one ragged tile: fewer macro steps than workgroups; three tiles with a ragged last one; 1000
+    leaves)."""
+    def grads(family, n):
+        if family == "pairs":
+            monkeypatch.setenv("VQHIP_TRAIN_WGRAD", "pairs")
+        else:
+            monkeypatch.delenv("VQHIP_TRAIN_WGRAD", raising=False)
+        c = HipCodec(weightpack.dumps(weights))
+        c.fulltrain_begin()
+        g = _hip_grads(c, weights, synth.make_leaves(n, seed=500 + n))
+        c.close()
+        return g
+    for n in (7, 65, 1000):
+        a, b = grads("pairs", n), grads("rows", n)
+        worst = max((float(np.abs(a[k] - b[k]).max() / max(np.abs(a[k]).max(), 1e-30)), k) for k in a if k.endswith("weight") and a[k].ndim == 5)
+        print(n, worst)
+        assert worst[0] < 2e-5, (n, worst)
+        for k in a:   # everything the two families do not touch is the same kernel: bit-identical
+            if not (k.endswith("weight") and a[k].ndim == 5):
+                assert np.array_equal(a[k], b[k]), (n, k)
+
+
 @pytest.mark.parametrize("folded", [True, False])
 def test_decoder_gradients_match_autograd(fcodec, ref_grads, weights, folded):
     """folded = the default: the tail (up_conv -> PixelShuffle3D -> final) as one folded operator, forward and backward, its parameter
