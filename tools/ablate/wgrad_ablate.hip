@@ -1,6 +1,7 @@
 // What bounds the weight-gradient kernel wgrad32_k (training, 43-51 % of the fp32 MFMA peak)?  Timing-only variants, one binary per -DWGRAD_ABL=n:
 //   for a in 0 1 2 4 5; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DWGRAD_ABL=$a -I vqvdb_amd/csrc tools/ablate/wgrad_ablate.hip -o tools/ablate/bin/ablate_wgrad_$a; done
-// WGRAD_ABL bits: 1 one global fetch only, 2 no MFMAs, 4 no LDS staging / barriers.
+// WGRAD_ABL bits: 1 one global fetch only, 2 no MFMAs, 4 no LDS staging / barriers.  -DROWS4_PIPE=0|1|2: operand read-ahead of wgrad_rows4_k
+// (0: 109.6 / 101.1 TFLOP/s for the stem / 64->64 layer at 8192 leaves, 1: 116.5 / 106.4, 2: 116.1 / 106.7).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -22,12 +22,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VQ_LT 32  // leaves per tile
 
-// Timing-only ablation switches (template parameter ABL of conv8_lds_k / conv_rows16_k, the STEM_DEPTH / WGRAD_ABL macros) exist
+// Timing-only ablation switches (template parameter ABL of conv8_lds_k / conv_rows16_k, the STEM_DEPTH / WGRAD_ABL / ROWS4_PIPE macros) exist
 // for tools/ablate/*.hip, which define VQ_ABLATE before including the kernel headers; a library build cannot instantiate them.
 #ifndef VQ_ABLATE
 #define VQ_ABLATE 0
-#if defined(STEM_DEPTH) || defined(WGRAD_ABL)
-#error "STEM_DEPTH / WGRAD_ABL are ablation switches: define VQ_ABLATE 1 (tools/ablate only)"
+#if defined(STEM_DEPTH) || defined(WGRAD_ABL) || defined(ROWS4_PIPE)
+#error "STEM_DEPTH / WGRAD_ABL / ROWS4_PIPE are ablation switches: define VQ_ABLATE 1 (tools/ablate only)"
 #endif
 #endif
 

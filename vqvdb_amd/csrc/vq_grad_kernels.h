@@ -798,6 +798,9 @@ struct Rows4Iter {   // position in the class-major macro-step order, and the st
 };
 // A 32 x 32 output (the encoder's residual block) would be ONE wave doing the staging and the MFMAs in turn; it is cut into four 16 x 16
 // quadrants on the 16x16x4 MFMA instead (Q16): four waves share the staged blocks, same flops per wave-cycle.
+#ifndef ROWS4_PIPE   // leaf pairs whose MFMA operands are requested ahead (tools/ablate/wgrad_ablate.hip: 0 = the compiler's schedule, 1, 2)
+#define ROWS4_PIPE 1
+#endif
 template <int CIN, int COUT>
 constexpr int rows4_threads() { return CIN == 32 && COUT == 32 ? 256 : (COUT / 32) * (CIN / 32) * 64; }
 template <int CIN, int COUT, int INMODE, int GIN>
@@ -940,6 +943,40 @@ __global__ __launch_bounds__((rows4_threads<CIN, COUT>())) void wgrad_rows4_k(Wg
 #pragma unroll 4
             for (int m = 0; m < 16; ++m) acc[1] = mfma32(sdy[cur][2 * m + rA][32 * cb + (lane & 31)], sx[cur][2 * m + rA][32 * ib + (lane & 31)], acc[1]);
         } else {
+#if ROWS4_PIPE
+            // operands of leaf pair m+1 requested before the MFMAs of pair m (hand-ordered LDS reads: the compiler issues a trip's reads only
+            // after the previous trip's MFMAs and then waits for them)
+            const unsigned ya = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)&sdy[cur][rA][32 * cb + (lane & 31)];
+            const unsigned xa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)&sx[cur][rA][32 * ib + (lane & 31)];
+            const unsigned yp = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)&sdy[prev][rA][32 * cb + (lane & 31)];
+            const unsigned xp = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)&sx[prev][rA][32 * ib + (lane & 31)];
+            constexpr int PD = ROWS4_PIPE;   // leaf pairs requested ahead
+            float o[PD + 1][4];
+#define R4(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#pragma unroll
+            for (int m = 0; m < PD; ++m) {
+                R4(o[m][0], ya, m * 2 * SDY * 4); R4(o[m][1], xa, m * 2 * SX * 4);
+                R4(o[m][2], yp, m * 2 * SDY * 4); R4(o[m][3], xp, m * 2 * SX * 4);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int c_ = m % (PD + 1), n_ = (m + PD) % (PD + 1);
+                if (m + PD < 16) {
+                    R4(o[n_][0], ya, (m + PD) * 2 * SDY * 4); R4(o[n_][1], xa, (m + PD) * 2 * SX * 4);
+                    R4(o[n_][2], yp, (m + PD) * 2 * SDY * 4); R4(o[n_][3], xp, (m + PD) * 2 * SX * 4);
+                }
+                // (LDS returns in order: everything but the reads of the pairs after m must have arrived)
+                const int newer = (16 - 1 - m < PD ? 16 - 1 - m : PD) * 4;
+                if (newer == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(o[c_][0]), "+v"(o[c_][1]), "+v"(o[c_][2]), "+v"(o[c_][3]));
+                acc[1] = mfma32(o[c_][0], o[c_][1], acc[1]);
+                acc[0] = mfma32(o[c_][0], o[c_][3], acc[0]);
+                acc[2] = mfma32(o[c_][2], o[c_][1], acc[2]);
+            }
+#undef R4
+#else
 #pragma unroll 4
             for (int m = 0; m < 16; ++m) {   // (four leaf pairs per trip: sixteen operand registers live, not sixty-four)
                 const float ac = sdy[cur][2 * m + rA][32 * cb + (lane & 31)], bc = sx[cur][2 * m + rA][32 * ib + (lane & 31)];
@@ -948,6 +985,7 @@ __global__ __launch_bounds__((rows4_threads<CIN, COUT>())) void wgrad_rows4_k(Wg
                 acc[0] = mfma32(ac, bp, acc[0]);
                 acc[2] = mfma32(ap, bc, acc[2]);
             }
+#endif
         }
         // end of the class segment (or of the slice): the three taps go to partial slot q + class
         const int c_now = itc.c;
