@@ -2,7 +2,9 @@
 """Throughput bench of the VQ-VAE leaf hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU, or as the
+     plain command above: with no WORLD_SIZE in the environment it starts its N ranks itself under torch.distributed.run on
+     127.0.0.1 and a free port, passes the one JSON line of rank 0 through on its own stdout and returns the launcher's exit code)
 
 A step = one pass of the hot path over one 65,536-leaf batch per GPU, inputs resident in HBM.
 N = 1: BASELINE configs[1] ("1xMI355X, 1M synthetic leaves, fp32 encoder+quantizer" = 16 such batches, cycled for K steps).
@@ -216,6 +218,24 @@ class _RehearsalCodec:
     def close(self): pass
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) started as ONE process: run the same command line as N ranks under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port).  The ranks inherit this process's stdout — rank 0's JSON line
+    is the only thing they write there (main() points every rank's fd 1 at stderr and keeps a duplicate for the line) — and
+    the launcher's exit code is returned unchanged."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")              # what torchrun would set (and warn about) itself
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +246,10 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory legs (host-pointer C ABI end to end; configs[2] .vqvdb streaming decode)")
     ap.add_argument("--file-leaves", type=int, default=4 * 1024 * 1024, help="leaves in the configs[2] .vqvdb file")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("VQ_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(self_launch(args.gpus))
 
     # Only the final JSON line may reach stdout.  Native libraries (RCCL prints its version banner with
     # NCCL_DEBUG=VERSION, which this image exports) write to fd 1 directly, so fd 1 is pointed at stderr
@@ -249,8 +273,8 @@ def main():
         torch.cuda.synchronize = lambda *a, **k: None
     dev_index = 0 if rehearsal else local
     dist = world > 1 or os.environ.get("VQ_BENCH_FORCE_DIST") == "1"   # the latter exercises the RCCL path with one rank
-    if not dist and args.gpus != 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if world != args.gpus and not os.environ.get("VQ_BENCH_FORCE_DIST"):
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     device = torch.device("cpu") if cpu_rehearsal else torch.device("cuda", dev_index)
     if not cpu_rehearsal:
         torch.cuda.set_device(device)

@@ -419,17 +419,17 @@ def test_small_batch_policy_setter(pack):
 
 def test_bench_two_rank_code_path_rehearsal():
     """bench.py's N > 1 path (rank-sharded seeds, barriers, max-over-ranks timing, all-reduce of the codebook statistics,
-    one JSON line from rank 0) launched exactly like the driver does, with two ranks sharing the one GPU of this box
-    (gloo instead of RCCL; the throughput of such a run means nothing)."""
+    one JSON line from rank 0) started as the PLAIN command `python bench.py --gpus 2` — bench.py launches its own ranks under
+    torch.distributed.run (the torchrun-launched form is covered on CPU by tests/test_sharding_gloo.py) — with two ranks sharing
+    the one GPU of this box (gloo instead of RCCL; the throughput of such a run means nothing)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VQ_BENCH_SINGLE_GPU_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VQ_BENCH_SINGLE_GPU_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -593,3 +593,85 @@ def test_orchestrator_loop_bench_harness(pack, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     legs = [(m.group(1), int(m.group(2)), int(m.group(3))) for m in hostbench.LOOP_RE.finditer(r.stdout)]
     assert legs == [(d, b, 20000) for b in (64, 1000, 8192) for d in ("compress", "decompress")], r.stdout
+
+
+def _distinct_batch(n):
+    """n DISTINCT leaves: half uniform noise, half background-dominated VDB-like leaves, interleaved so that every tile mixes both."""
+    a, b = synth.make_leaves(n // 2, seed=4242), synth.sparse_leaves(n - n // 2, seed=4343)
+    x = np.empty((n, 512), dtype=np.float32)
+    x[0::2], x[1::2] = a, b
+    return x
+
+
+@pytest.mark.parametrize("regime", ["seed0", "trained"])
+def test_full_size_batch_of_distinct_leaves_every_leaf_vs_oracle(regime, oracle, weights):
+    """One 65 536-leaf batch in which EVERY tile differs, through the default (one-workgroup-per-tile / persistent) kernels of a full
+    chunk — conv8_lds_k's loop across half-tile boundaries, stem_taps_k's ring, the row kernels — compared with the oracle leaf for
+    leaf: every index, every voxel, bit for bit.  On the synthetic seed-0 weights and on the checkpoint the reference's own
+    optimisation step produced (tests/golden/golden_regimes_v1.npz)."""
+    import os
+    from conftest import ROOT
+    from oracle.oracle import Oracle
+    if regime == "seed0":
+        w, orc = weights, oracle
+    else:
+        from test_golden_regimes import regime_weights
+        w = regime_weights(np.load(os.path.join(ROOT, "tests", "golden", "golden_regimes_v1.npz")), regime)
+        orc = Oracle(w, [t[0] for t in synth.TENSORS])
+    n = 65536
+    x = _distinct_batch(n)
+    assert len(np.unique(x[:, :8].view(np.uint64).sum(axis=1))) > n * 0.9      # the batch really is made of distinct leaves
+    c = HipCodec(weightpack.dumps(w))
+    c.set_chunk_leaves(n)
+    threads = len(os.sched_getaffinity(0))
+    idx = c.encode(x)
+    oidx = orc.encode(x, threads=threads)
+    bad = np.nonzero((idx != oidx).any(axis=1))[0]
+    assert len(bad) == 0, (regime, len(bad), bad[:8])
+    rec = c.decode(idx)
+    orec = orc.decode(oidx, threads=threads)
+    badv = np.nonzero((_bits(rec) != _bits(orec)).any(axis=1))[0]
+    assert len(badv) == 0, (regime, len(badv), badv[:8])
+    c.close()
+
+
+def test_fuzz_slice_launch_paths_agree_bit_for_bit():
+    """60 seconds of tools/fuzz_paths.py (random batch sizes 1 ... 70 000 through the default policy, one wave per tile everywhere,
+    position-split everywhere; both decoder fronts; adversarial leaves mixed in) — the evidence belongs in the GPU test record,
+    not in a log."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_paths.py"), "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert "fuzz ok" in r.stdout
+    rounds = int(r.stdout.split("fuzz ok:")[1].split("rounds")[0])
+    assert rounds > 100, r.stdout
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_failed_workspace_allocation_leaves_the_handle_usable(pack, oracle):
+    """a workspace hipMalloc that fails must (a) fail THAT call with the out-of-memory error, (b) not leave its error in
+    the runtime's sticky last-error slot where the next launch check would read it, (c) let the next call succeed."""
+    import torch
+    dev = torch.device("cuda", 0)
+    c = HipCodec(pack)
+    c.set_chunk_leaves(65536)
+    x = synth.make_leaves(64, seed=3)
+    want = oracle.encode(x, threads=8)
+    assert np.array_equal(c.encode(x), want)              # chunk fitted to the free memory NOW (plenty), small workspace allocated
+    big = torch.rand(65536, 512, device=dev)
+    out = torch.empty(65536, 64, device=dev, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    hog = torch.empty(free_b - (1 << 30), dtype=torch.uint8, device=dev)   # leave 1 GiB: the 6.8 GB workspace of a full chunk cannot fit
+    with pytest.raises(RuntimeError, match="hipMalloc"):
+        c.encode_device(big.data_ptr(), 65536, out.data_ptr(), 0)
+    del hog
+    torch.cuda.empty_cache()
+    assert np.array_equal(c.encode(x), want)              # the very next call: no stale "out of memory" from the failed allocation
+    c.encode_device(big.data_ptr(), 65536, out.data_ptr(), 0)   # and the full chunk fits again
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:64].cpu().numpy(), oracle.encode(big[:64].cpu().numpy(), threads=8))
+    c.close()

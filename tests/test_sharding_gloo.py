@@ -99,3 +99,25 @@ def test_bench_n_gt_1_protocol_and_json_shape_without_a_gpu():
     assert abs(d["ms_per_step"] * d["steps"] * 1e-3 * d["value"] - 2 * 128 * 65536) < 1e-3 * 2 * 128 * 65536
     assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["unit"] == "TFLOP/s" and d["roofline"]["bound"] == "mfma"
     assert d["host_path"] and "skipped" in d["host_path"]
+
+
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as ONE plain process (no torch.distributed.run, no WORLD_SIZE in the environment — the shape of
+    the driver's N = 1 command): bench.py starts its two ranks itself, exactly one JSON line reaches the original stdout, the
+    exit code is the launcher's."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VQ_BENCH_CPU_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["collective_backend"] == "gloo" and d["steps"] == 128
+    assert [o["rank"] for o in d["devices_seen"]] == [0, 1]
+    # a rank that fails takes the command down with a non-zero exit code and no JSON line
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--bogus-flag"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

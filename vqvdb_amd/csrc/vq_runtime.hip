@@ -231,6 +231,7 @@ namespace {
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
+            (void)hipGetLastError(); /* the slot is sticky until read: do not let it fail the next launch check */ \
             (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
             return VQHIP_ERR_DEVICE;                                                            \
         }                                                                                       \
@@ -778,10 +779,14 @@ int ensure_workspace(vqhip_codec* c, int64_t n_leaves)
     }
     size_t total = workspace_bytes(new_tiles, full);
     hipError_t e = hipMalloc(&c->ws, total);
+    // a failed hipMalloc leaves its error in the thread's last-error slot (ROCm 7.2 keeps it until it is read): clear it, or the next
+    // launch check reads "out of memory" for a launch that succeeded and turns a good retry / the promised smaller-chunk call into a failure
+    if (e != hipSuccess) (void)hipGetLastError();
     if (e != hipSuccess && new_tiles > tiles) {   // the larger-than-needed size did not fit: what the call needs
         new_tiles = tiles;
         total = workspace_bytes(new_tiles, full);
         e = hipMalloc(&c->ws, total);
+        if (e != hipSuccess) (void)hipGetLastError();
     }
     if (e != hipSuccess) {
         // the handle holds no workspace now (ws_bytes 0, every activation pointer null); the chunk is re-fitted to the free memory
