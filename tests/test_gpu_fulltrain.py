@@ -393,3 +393,53 @@ def test_checkpoint_resumes_optimizer_and_schedule(weights):
     for _ in range(2):
         d.step(x, want_metrics=False)
     assert not np.array_equal(d.checkpoint()["encoder.pre.0.weight"], sa["encoder.pre.0.weight"])
+
+
+def test_five_steps_against_the_references_own_optimizer_loop(weights):
+    """FullTrainer against tests/golden/golden_trainloop_v1.npz: five steps of the IMPORTED reference's loop with torch.optim.AdamW +
+    CosineAnnealingLR stepped per batch (python/training.py:98-101,136-164; generator tests/golden/make_golden_trainloop.py).
+    Per step: loss pieces, perplexity, learning rate, the EMA codebook and cluster sizes.  Step 1: the FULL gradient of six tensors
+    (first conv, a 16->16 conv, down, proj, stem, up_conv) at the fp64-test bar against the reference evaluated in fp64 (the batch
+    keeps every ReLU input >= 2e-6 from zero), and against the reference's fp32 autograd.  After step 5: the six tensors within Adam's
+    sign-step bound, every tensor's norm."""
+    import os
+    from conftest import ROOT
+    from vqvdb_amd.full_training import FullTrainer, flat_to_dict
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "golden_trainloop_v1.npz"))
+    c = HipCodec(weightpack.dumps(weights))
+    tr = FullTrainer(c, t_max=int(fx["t_max"]))
+    six = [k[4:] for k in fx.files if k.startswith("g64/")]
+    assert len(six) == 6
+    for s, seed in enumerate(fx["seeds"].tolist()):
+        x = torch.from_numpy(synth.make_leaves(64, seed=int(seed))).cuda()
+        m = tr.step(x)
+        torch.cuda.synchronize()
+        assert abs(m["lr"] - float(fx[f"s{s}/lr"])) < 1e-12, (s, m["lr"])
+        for k, key in (("loss", "loss"), ("recon_mse", "mse"), ("recon_l1", "l1"), ("vq_loss", "vq_loss")):
+            assert abs(m[k] - float(fx[f"s{s}/{key}"])) < 2e-5 * abs(float(fx[f"s{s}/{key}"])), (s, k, m[k], float(fx[f"s{s}/{key}"]))
+        assert abs(m["perplexity"] - float(fx[f"s{s}/perplexity"])) < 1e-4 * float(fx[f"s{s}/perplexity"]), (s, m["perplexity"])
+        if s == 0:
+            g = flat_to_dict(tr.grads.cpu().numpy())
+            worst = []
+            for name in six:
+                e64, e32 = _rel(g[name], fx["g64/" + name]), _rel(g[name], fx["g32/" + name])
+                worst.append((name, f"{e64:.1e}", f"{e32:.1e}", f"{_rel(fx['g32/' + name], fx['g64/' + name]):.1e}"))
+                assert e64 < GRAD_VS_FP64 and e32 < 2 * GRAD_VS_FP64, (name, e64, e32)
+            for name in [k[5:] for k in fx.files if k.startswith("gsum/")]:
+                want = fx["gsum/" + name]
+                assert abs(float(np.linalg.norm(g[name].astype(np.float64))) - want[1]) < 1e-4 * want[1], name
+                assert abs(float(np.abs(g[name]).max()) - want[2]) < 1e-4 * want[2], name
+            print("step-1 gradients, relative to each tensor's max (HIP vs reference fp64, HIP vs reference fp32, reference fp32 vs its fp64):", worst)
+        st = c.train_get_state()
+        assert _rel(st["cluster_size"], fx[f"s{s}/cluster_size"]) < 1e-6, s
+        assert _rel(st["embedding"], fx[f"s{s}/embedding"]) < 1e-4, s
+    sd = tr.state_dict()
+    lr0 = 1e-4
+    for name in six:
+        diff = np.abs(sd[name] - fx["p5/" + name])
+        # Adam's first steps move every element by ~lr whatever the gradient's size, so an element whose gradient is zero within
+        # rounding may differ by up to 2 lr per step; the bulk must agree far better than that
+        assert diff.max() <= 10.5 * lr0 and diff.mean() < 0.05 * lr0, (name, float(diff.max()), float(diff.mean()))
+    for name in [k[5:] for k in fx.files if k.startswith("psum/")]:
+        assert abs(float(np.linalg.norm(sd[name].astype(np.float64))) - fx["psum/" + name][1]) < 1e-4 * max(fx["psum/" + name][1], 1e-3), name
+    c.close()

@@ -620,7 +620,7 @@ def test_full_size_batch_of_distinct_leaves_every_leaf_vs_oracle(regime, oracle,
         orc = Oracle(w, [t[0] for t in synth.TENSORS])
     n = 65536
     x = _distinct_batch(n)
-    assert len(np.unique(x[:, :8].view(np.uint64).sum(axis=1))) > n * 0.9      # the batch really is made of distinct leaves
+    assert len(np.unique(x.view(np.dtype((np.void, 2048))).ravel())) > n * 0.9      # distinct leaves (the sparse half holds some exact-zero leaves)
     c = HipCodec(weightpack.dumps(w))
     c.set_chunk_leaves(n)
     threads = len(os.sched_getaffinity(0))
@@ -653,25 +653,35 @@ def test_fuzz_slice_launch_paths_agree_bit_for_bit():
 
 def test_failed_workspace_allocation_leaves_the_handle_usable(pack, oracle):
     """a workspace hipMalloc that fails must (a) fail THAT call with the out-of-memory error, (b) not leave its error in
-    the runtime's sticky last-error slot where the next launch check would read it, (c) let the next call succeed."""
-    import torch
-    dev = torch.device("cuda", 0)
+    the runtime's sticky last-error slot where the next launch check would read it, (c) let the next call succeed.  Device memory is
+    hogged through the HIP runtime this process already has loaded (ctypes), not through torch: a second runtime in one process sees no GPU."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+
+    def malloc(n):
+        p = vp()
+        assert hip.hipMalloc(ctypes.byref(p), sz(n)) == 0, n
+        return p
     c = HipCodec(pack)
     c.set_chunk_leaves(65536)
     x = synth.make_leaves(64, seed=3)
     want = oracle.encode(x, threads=8)
     assert np.array_equal(c.encode(x), want)              # chunk fitted to the free memory NOW (plenty), small workspace allocated
-    big = torch.rand(65536, 512, device=dev)
-    out = torch.empty(65536, 64, device=dev, dtype=torch.uint8)
-    torch.cuda.synchronize()
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    hog = torch.empty(free_b - (1 << 30), dtype=torch.uint8, device=dev)   # leave 1 GiB: the 6.8 GB workspace of a full chunk cannot fit
+    big = np.tile(synth.make_leaves(4096, seed=4), (16, 1))
+    d_in, d_out = malloc(big.nbytes), malloc(65536 * 64)
+    assert hip.hipMemcpy(d_in, vp(big.ctypes.data), sz(big.nbytes), 1) == 0
+    free_b, total_b = sz(), sz()
+    assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+    hog = malloc(free_b.value - (1 << 30))                # leave 1 GiB: the 6.8 GB workspace of a full chunk cannot fit
     with pytest.raises(RuntimeError, match="hipMalloc"):
-        c.encode_device(big.data_ptr(), 65536, out.data_ptr(), 0)
-    del hog
-    torch.cuda.empty_cache()
+        c.encode_device(d_in.value, 65536, d_out.value, 0)
+    assert hip.hipFree(hog) == 0
     assert np.array_equal(c.encode(x), want)              # the very next call: no stale "out of memory" from the failed allocation
-    c.encode_device(big.data_ptr(), 65536, out.data_ptr(), 0)   # and the full chunk fits again
-    torch.cuda.synchronize()
-    assert np.array_equal(out[:64].cpu().numpy(), oracle.encode(big[:64].cpu().numpy(), threads=8))
+    c.encode_device(d_in.value, 65536, d_out.value, 0)    # and the full chunk fits again
+    assert hip.hipDeviceSynchronize() == 0
+    got = np.empty((64, 64), dtype=np.uint8)
+    assert hip.hipMemcpy(vp(got.ctypes.data), d_out, sz(got.nbytes), 2) == 0
+    assert np.array_equal(got, oracle.encode(big[:64], threads=8))
+    hip.hipFree(d_in), hip.hipFree(d_out)
     c.close()
