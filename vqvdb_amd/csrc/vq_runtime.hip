@@ -884,6 +884,9 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 // kernel instantiations -------------------------------------------------------------------
 //                                          CIN COUT NPI NPO NW STREAM KWG INMODE GIN RESID GOUT CSUM  OUTMODE
 //                                        CIN COUT SI SO KS ST PD NW INMODE GIN RESID GOUT CSUM
+// decoder front of full chunks: gathers row by row (PIPE 0: the tap loop is bound by the LDS itself, reads in flight ahead bought nothing),
+// the two position halves of a leaf octet on one SIMD (HMAP 1), the first taps of a pass not waiting for the previous pass's stores (RELAX)
+constexpr auto k_stem_taps = stem_taps_k<0, 1, 0, true, 0>;
 constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
 //                                           CIN COUT SI SO KS ST PD INMODE RESID GOUT CSUM
 // large passes: kw-outer MFMA order (A fragments of a (kw, channel-block pair) read once for every output of the row)
@@ -941,7 +944,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, conv8_lds_k<false, true, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
-    if ((rc = set_lds(c, stem_taps_k, LDS_STEM_TAPS))) return rc;
+    if ((rc = set_lds(c, k_stem_taps, LDS_STEM_TAPS))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<4>, LDS_LATENT))) return rc;
@@ -1234,7 +1237,7 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         F.idx = d_idx, F.T = w["ds.lut"], F.bias = w["ds.b"], F.gamma = w["dg0.w"], F.beta = w["dg0.b"], F.d2 = a["d_d2"];
         F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
         F.n_leaves = n, F.n_tiles = nt;
-        L.run("dec_stem_gn_s", [&] { hipLaunchKernelGGL(stem_taps_k, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
+        L.run("dec_stem_gn_s", [&] { hipLaunchKernelGGL(k_stem_taps, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
     } else {
         L.run("dec_stem_s", [&] {
             hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt, split_factor(2 * nt, 2, 16, 2048)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
@@ -1310,7 +1313,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
         F.steps = (const int4*)w["steps.k3s1_4"], F.grp_start = reinterpret_cast<const int*>(w["steps.k3s1_4.grp"]), F.n_steps = c->nsteps["steps.k3s1_4"];
         F.n_leaves = n, F.n_tiles = nt;
-        if (c->stem_taps) L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_taps_k, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
+        if (c->stem_taps) L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(k_stem_taps, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
         else L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_fused_k, dim3(8 * nt), dim3(512), 0, s, F); });
     } else {
         L.run("dec_stem", [&] {

@@ -41,8 +41,24 @@ __device__ __forceinline__ unsigned lds_u32_read(unsigned byte_addr)
     return v;
 }
 
+// lgkmcnt-only wait: LDS reads return in order, so "at most N outstanding" = "all but the N youngest have landed"
+template <int N>
+__device__ __forceinline__ void lds_frags_wait_n() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// PIPE: rows of a tap whose gather reads are in flight ahead of the row being accumulated (0 = read, wait, add, row by row — round 3).
+// HMAP: wave -> (leaf octet, position half): 0 = (w >> 1, w & 1); 1 = (w & 3, w >> 2), so that the two waves of a SIMD (w and w + 4)
+// are the two position halves of one octet — for kd = 0 / kd = 2 one half has half the rows of the other, and the per-tap barrier
+// makes a SIMD that hosts two light waves wait for one that hosts two heavy ones.
+// RELAX: the first three taps of a pass wait for their own table slices only, not for the previous pass's output stores (which are
+// younger than those slices in the wave's vector-memory queue: vmcnt counts in order).  STAG: workgroups start in four groups
+// STAG x 4096 cycles apart, so that the 256 KB output bursts of the chip's 256 workgroups — every pass ends with one, and the passes
+// of a persistent launch are equally long, i.e. stay in lockstep — do not hit HBM at the same moment.
+// ABL (tools/ablate only): 1 no gather reads, 2 no adds, 4 no table DMA, 8 no epilogue, 16 no per-tap barrier, 32 no output stores.
+template <int PIPE = 0, int HMAP = 0, int ABL = 0, bool RELAX = false, int STAG = 0>
 __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
 {
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
+    static_assert(PIPE >= 0 && PIPE <= 2, "0, 1 or 2 rows ahead");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* ring = (f32x4*)smem_raw;                                  // [4 slots][256 codes][8 chunks]
     unsigned char* sidx = smem_raw + 4 * 32768;                      // [32 leaves][128]: codes at bytes 32 .. 95
@@ -50,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
     const unsigned ring_off = lds_offset_of(ring), sidx_off = lds_offset_of(sidx);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int oct = wave >> 1, h = wave & 1;
+    const int oct = HMAP ? (wave & 3) : (wave >> 1), h = HMAP ? (wave >> 2) : (wave & 1);
     const int l = lane >> 3, c = lane & 7;
     const int jt = 8 * oct + l;                                       // leaf of this lane in the tile
     const unsigned nb_addr = sidx_off + (unsigned)(jt * 128 + 32 + 32 * h);
@@ -61,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
     const vq_buf tb = buf_of(A.T);
     const unsigned lane_t = (unsigned)((lane >> 3) * 64 + (lane & 7) * 4) * 4u;
     auto issue_slice = [&](int t, int half, int slot) {
+        if (ABL & 4) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = k * 8 + wave;
@@ -75,6 +92,11 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
 #pragma unroll
         for (int b = 0; b < 4; ++b) sidx[li * 128 + 32 + b0 + b] = leaf < A.n_leaves ? A.idx[leaf * 64 + b0 + b] : (unsigned char)0;
     };
+    if (STAG > 0) {
+        const int g = ((int)blockIdx.x >> 3) & 3;   // (eight consecutive workgroups = one per XCD)
+        for (int i = 0; i < g * STAG; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles
+    }
+    bool after_stores = false;   // (wave-uniform) has this wave's queue output stores behind the first three slices of the pass?
     if ((int)blockIdx.x < A.n_tiles) {
         stage_codes(blockIdx.x);
         issue_slice(0, 0, 0);
@@ -101,16 +123,22 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                 bool rv[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) rv[r] = (unsigned)(2 * h + (r >> 2) + kd - 1) < 4u && (unsigned)((r & 3) + kh - 1) < 4u;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
+                auto tap = [&](auto KW) {   // kw as a compile-time constant: the reads per row (and the wait counts) depend on it
+                    constexpr int kw = decltype(KW)::value;
                     const int t = kdkh * 3 + kw;
                     // this wave's pieces of slice t have landed (two newer slices = 8 DMA instructions may still be in flight; the first
                     // three slices of a pass were requested before the previous pass's epilogue, whose stores are younger: wait for all)
+                    // RELAX: slices 0-2 were requested BEFORE the previous pass's 32 output stores per wave: "all but the youngest 8 + 32"
+                    if (RELAX && t <= 2) {
+                        if (after_stores && !A.ystem_dbg) __builtin_amdgcn_s_waitcnt(0x8F78);   // vmcnt(40)
+                        else if (t == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+                        else __builtin_amdgcn_s_waitcnt(0x0F78);
+                    } else
                     if (t == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
                     else if (t <= 24) __builtin_amdgcn_s_waitcnt(0x0F78);
                     else if (t == 25) __builtin_amdgcn_s_waitcnt(0x0F74);
                     else __builtin_amdgcn_s_waitcnt(0x0F70);
-                    __builtin_amdgcn_s_barrier();   // slice t visible to every wave; every wave is done with slice t - 1's slot
+                    if (!(ABL & 16)) __builtin_amdgcn_s_barrier();   // slice t visible to every wave; every wave is done with slice t - 1's slot
                     asm volatile("" ::: "memory");
                     if (t + 3 <= 26) issue_slice(t + 3, half, (t + 3) & 3);
                     const unsigned wbase = ring_off + (unsigned)(t & 3) * 32768u + (unsigned)c * 16u;
@@ -119,30 +147,65 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
 #pragma unroll
                         for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(nb[r]));
                     }
+                    // one row's gather: the (up to) four neighbour codes' 16-byte chunks of this lane; NRD reads per row (static per kw)
+                    constexpr int NRD = kw == 1 ? 4 : 3;
+                    f32x4 rowb[PIPE + 1][4];
+                    auto issue_row = [&](int r, f32x4 (&row)[4]) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (rv[r]) {   // (wave-uniform)
-                            f32x4 row[4];
+                        for (int pw = 0; pw < 4; ++pw) {
+                            const int qw = pw + kw - 1;
+                            if (qw < 0 || qw > 3) continue;   // (static) zero padding along w
+                            if (ABL & 1) row[pw] = b4;
+                            else row[pw] = lds_frag_read(wbase + ((nb[r] >> (8 * qw)) & 0xffu) * 128u);
+                        }
+                    };
+                    auto add_row = [&](int r, f32x4 (&row)[4]) {
 #pragma unroll
-                            for (int pw = 0; pw < 4; ++pw) {
-                                const int qw = pw + kw - 1;
-                                if (qw < 0 || qw > 3) continue;   // (static) zero padding along w
-                                row[pw] = lds_frag_read(wbase + ((nb[r] >> (8 * qw)) & 0xffu) * 128u);
+                        for (int pw = 0; pw < 4; ++pw) {
+                            const int qw = pw + kw - 1;
+                            if (qw < 0 || qw > 3) continue;
+                            lds_frag_use(row[pw]);
+                            if (ABL & 2) acc[4 * r + pw].x = row[pw].x;
+                            else acc[4 * r + pw] = acc[4 * r + pw] + row[pw];
+                        }
+                    };
+                    if (PIPE == 0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if (rv[r]) {   // (wave-uniform)
+                                issue_row(r, rowb[0]);
+                                lds_frags_wait();
+                                add_row(r, rowb[0]);
                             }
-                            lds_frags_wait();
+                        }
+                    } else {
+                        // rows PIPE ahead: row r's reads are issued, then row r - PIPE is accumulated once everything older than the
+                        // (valid) rows issued since has landed.  Buffers are indexed statically by r; rv[] is wave-uniform, so the
+                        // wait counts are picked by scalar branches.  Per accumulator the taps still arrive in ascending order.
 #pragma unroll
-                            for (int pw = 0; pw < 4; ++pw) {
-                                const int qw = pw + kw - 1;
-                                if (qw < 0 || qw > 3) continue;
-                                lds_frag_use(row[pw]);
-                                acc[4 * r + pw] = acc[4 * r + pw] + row[pw];
+                        for (int r = 0; r < 8 + PIPE; ++r) {
+                            if (r < 8 && rv[r]) issue_row(r, rowb[r % (PIPE + 1)]);
+                            const int rc = r - PIPE;
+                            if (rc >= 0 && rv[rc]) {
+                                int younger = 0;   // valid rows issued after rc (each NRD reads)
+#pragma unroll
+                                for (int k = 1; k <= PIPE; ++k) younger += (rc + k < 8 && rv[rc + k]) ? 1 : 0;
+                                if (younger == 0) lds_frags_wait_n<0>();
+                                else if (younger == 1) lds_frags_wait_n<NRD>();
+                                else lds_frags_wait_n<2 * NRD>();
+                                add_row(rc, rowb[rc % (PIPE + 1)]);
                             }
                         }
                     }
-                }
+                };
+                tap(std::integral_constant<int, 0>{});
+                tap(std::integral_constant<int, 1>{});
+                tap(std::integral_constant<int, 2>{});
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();   // every wave is done with the ring and with the tile's codes; no DMA in flight
+            // (this pass's GroupNorm affine first: requested after the slices, their first use would wait for the slices as well)
+            const f32x4 gm4 = ((const f32x4*)A.gamma)[cg], bt4 = ((const f32x4*)A.beta)[cg];
             // the NEXT pass's first three slices (and, at a tile change, its codes) travel while this pass's statistics and stores run
             {
                 const int ntile = half == 0 ? tile : tile + (int)gridDim.x;
@@ -154,7 +217,15 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                 }
             }
 
-            // ---- statistics of y = acc + bias (as in stem_taps_k) ----
+            if (ABL & 8) {   // keep the accumulators alive, nothing else
+                float t = 0.0f;
+#pragma unroll
+                for (int p = 0; p < 32; ++p) t += acc[p].x + acc[p].w;
+                if (t == 12345.678f) A.d2[tid] = t;
+                __syncthreads();
+                continue;
+            }
+            // ---- statistics of y = acc + bias (as in stem_fused_k) ----
             double bs[8], bq[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -198,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                 gn_finish((c & 1) ? S2 + S : S + S2, (c & 1) ? Q2 + Q : Q + Q2, 1.0 / 512.0, m, r);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ia[i] = r * A.gamma[4 * cg + i];
-                    ib[i] = __builtin_fmaf(-m, ia[i], A.beta[4 * cg + i]);
+                    ia[i] = r * gm4[i];
+                    ib[i] = __builtin_fmaf(-m, ia[i], bt4[i]);
                 }
             }
             {
@@ -220,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                         y.y = fmaxf(__builtin_fmaf(v.y, ia[1], ib[1]), 0.0f);
                         y.z = fmaxf(__builtin_fmaf(v.z, ia[2], ib[2]), 0.0f);
                         y.w = fmaxf(__builtin_fmaf(v.w, ia[3], ib[3]), 0.0f);
-                        buf_st16_nt(y, outb, lane_o, po * 8192u);
+                        if (!(ABL & 32)) buf_st16_nt(y, outb, lane_o, po * 8192u);
                         st.add(y.x);
                         st.add(y.y);
                         st.add(y.z);
@@ -240,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                     A.out_rstd[((size_t)tile * 8 + (cg >> 1)) * 32 + jt] = r;
                 }
             }
+            after_stores = true;
             __syncthreads();   // the next pass reads the codes staged above
         }
     }
