@@ -54,11 +54,14 @@ def test_encode_bit_exact_vs_oracle_all_layers(codec, oracle):
 
 def test_decode_bit_exact_vs_oracle_all_layers(codec, oracle, golden):
     idx = np.concatenate([golden["idx_rand"][:100], golden["idx_edge"]])
+    codec.debug_enable(True)       # every intermediate at its own address; the one-kernel decoder front then also stores the raw stem output
     rec = codec.decode(idx)
     orec, dbg = oracle.decode(idx, threads=8, debug=DEC_DEBUG)
     for name in ["d_ystem", "d_d2", "d_y4", "d_x6"]:
         c, p = DEBUG_SHAPES[name]
         assert np.array_equal(_bits(codec.debug_fetch(name, len(idx), c, p)), _bits(dbg[name])), name
+    codec.debug_enable(False)
+    assert np.array_equal(_bits(codec.decode(idx)), _bits(rec))      # the same voxels without the debug stores
     assert np.array_equal(_bits(rec), _bits(orec))
     assert float((np.abs(rec - orec) / np.abs(orec)).max()) < TOL     # the stated tolerance, trivially met
 

@@ -1682,8 +1682,13 @@ struct StemFusedArgs {
 #ifndef STEM_DEPTH
 #define STEM_DEPTH 8
 #endif
-__global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
+// NW waves per workgroup: 8 (eight positions = two statistics blocks per wave) for full chunks; 16 (four positions = one block per wave,
+// half the serial gather chain) for SOP-sized passes, where a handful of workgroups is all there is and the chain is the latency
+template <int NW = 8>
+__global__ __launch_bounds__(NW * 64) void stem_fused_k(StemFusedArgs A)
 {
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    constexpr int PW = 64 / NW, BW = PW / 4;   // positions / statistics blocks per wave
     __shared__ f32x4 ys[64 * 4 * 16];          // [pos][leaf 4][chunk 16]
     __shared__ double part[16][64];            // [block][lane of (leaf, chunk)]: the sums, then (after a barrier) the sums of squares —
                                                // 8 KB instead of 16: 74 KB per workgroup, two workgroups per CU
@@ -1705,13 +1710,15 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
     double bs0 = 0.0, bq0 = 0.0, bs1 = 0.0, bq1 = 0.0;   // this wave's two blocks (2w, 2w+1) of the tensor being reduced
     // ordered sum of the 16 blocks of every lane's accumulator: sums through LDS, barrier, sums of squares through the same buffer
     auto ordered_totals = [&](double& S, double& Q) {
-        part[2 * wave][lane] = bs0, part[2 * wave + 1][lane] = bs1;
+        part[BW * wave][lane] = bs0;
+        if (BW == 2) part[2 * wave + 1][lane] = bs1;
         __syncthreads();
         S = 0.0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) S += part[b][lane];
         __syncthreads();
-        part[2 * wave][lane] = bq0, part[2 * wave + 1][lane] = bq1;
+        part[BW * wave][lane] = bq0;
+        if (BW == 2) part[2 * wave + 1][lane] = bq1;
         __syncthreads();
         Q = 0.0;
 #pragma unroll
@@ -1719,7 +1726,7 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
         __syncthreads();
     };
     {
-        const int g0 = wave * 8, g1 = g0 + 8;
+        const int g0 = wave * PW, g1 = g0 + PW;
         int si = A.grp_start[g0];
         const int NSm = A.n_steps - 1;
         // D - 1 table rows in flight per wave (ring of D registers and D schedule entries, static indices).  The gather is bound by the
@@ -1758,7 +1765,7 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
                         st.add(v.w);
                         acc = (f32x4){0, 0, 0, 0};
                         if ((po & 3) == 3) {
-                            if (po & 4) bs1 = st.bs, bq1 = st.bq;
+                            if ((po >> 2) & (BW - 1)) bs1 = st.bs, bq1 = st.bq;
                             else bs0 = st.bs, bq0 = st.bq;
                             st.init();
                         }
@@ -1790,8 +1797,8 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
         GnAcc st;
         st.init();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int po = wave * 8 + k;
+        for (int k = 0; k < PW; ++k) {
+            const int po = wave * PW + k;
             const f32x4 v = ys[(po * 4 + l) * 16 + c];
             if (dbg4) dbg4[(size_t)po * 16 * 32] = v;
             f32x4 y;
@@ -1805,7 +1812,7 @@ __global__ __launch_bounds__(512) void stem_fused_k(StemFusedArgs A)
             st.add(y.z);
             st.add(y.w);
             if ((k & 3) == 3) {
-                if (k & 4) bs1 = st.bs, bq1 = st.bq;
+                if ((k >> 2) & (BW - 1)) bs1 = st.bs, bq1 = st.bq;
                 else bs0 = st.bs, bq0 = st.bq;
                 st.init();
             }

@@ -1238,6 +1238,19 @@ int decode_chunk_split(vqhip_codec* c, Launcher& L, const uint8_t* d_idx, int64_
         F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
         F.n_leaves = n, F.n_tiles = nt;
         L.run("dec_stem_gn_s", [&] { hipLaunchKernelGGL(k_stem_taps, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
+    } else if (c->stem_fused && getenv("VQHIP_STEM_SMALL") == nullptr) {
+        // SOP-sized passes: the decoder front as ONE kernel too — a workgroup per four leaves gathers its table rows through the L1,
+        // normalises out of LDS and finishes both sets of statistics itself (stem_fused_k) — instead of gather + combine + normalise +
+        // combine (four launches of 6-23 us each at 64 leaves); same d2 and statistics bit for bit
+        StemFusedArgs F{};
+        F.idx = d_idx, F.T = w["ds.lut"], F.bias = w["ds.b"], F.gamma = w["dg0.w"], F.beta = w["dg0.b"], F.d2 = a["d_d2"];
+        F.out_mean = a["st_b.mean"], F.out_rstd = a["st_b.rstd"], F.ystem_dbg = c->debug ? a["d_ystem"] : nullptr;
+        F.steps = (const int4*)w["steps.k3s1_4"], F.grp_start = reinterpret_cast<const int*>(w["steps.k3s1_4.grp"]), F.n_steps = c->nsteps["steps.k3s1_4"];
+        F.n_leaves = n, F.n_tiles = nt;
+        L.run("dec_stem_gn_s", [&] {
+            if (nt <= 64) hipLaunchKernelGGL(stem_fused_k<16>, dim3(8 * nt), dim3(1024), 0, s, F);   // up to 2048 leaves: sixteen waves, half the gather chain each
+            else hipLaunchKernelGGL(stem_fused_k<8>, dim3(8 * nt), dim3(512), 0, s, F);
+        });
     } else {
         L.run("dec_stem_s", [&] {
             hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt, split_factor(2 * nt, 2, 16, 2048)), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], (float*)nullptr, (float*)nullptr,
@@ -1314,7 +1327,7 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         F.steps = (const int4*)w["steps.k3s1_4"], F.grp_start = reinterpret_cast<const int*>(w["steps.k3s1_4.grp"]), F.n_steps = c->nsteps["steps.k3s1_4"];
         F.n_leaves = n, F.n_tiles = nt;
         if (c->stem_taps) L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(k_stem_taps, dim3(std::min(nt, c->n_cus)), dim3(512), LDS_STEM_TAPS, s, F); });
-        else L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_fused_k, dim3(8 * nt), dim3(512), 0, s, F); });
+        else L.run("dec_stem_gn", [&] { hipLaunchKernelGGL(stem_fused_k<8>, dim3(8 * nt), dim3(512), 0, s, F); });
     } else {
         L.run("dec_stem", [&] {
             hipLaunchKernelGGL(stem_lut_k, dim3(2 * nt), dim3(256), 0, s, d_idx, w["ds.lut"], w["ds.b"], a["d_ystem"], a["st_a.mean"], a["st_a.rstd"],
