@@ -55,6 +55,8 @@ int main()
 #define R(RESID, STATS, CSUM, ABL) run("conv4_lds_k RESID " #RESID " STATS " #STATS " CSUM " #CSUM " ABL " #ABL, conv4_lds_k<RESID, STATS, CSUM, ABL>, A, cus, 512, LDS_CONV4)
     // ABL bits: 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads, 32 no MFMAs
     R(false, true, false, 0); R(true, false, true, 0); R(false, true, false, 0); R(true, false, true, 0);
+#define RS(RESID, STATS, CSUM, STG) run("conv4_lds_k RESID " #RESID " STATS " #STATS " CSUM " #CSUM " STG " #STG, conv4_lds_k<RESID, STATS, CSUM, 0, STG>, A, cus, 512, LDS_CONV4)
+    RS(false, true, false, 0); RS(true, false, true, 0); RS(false, true, false, 1); RS(true, false, true, 1); RS(false, true, false, 0); RS(true, false, true, 0);
     R(false, true, false, 1); R(false, true, false, 2); R(false, true, false, 4); R(false, true, false, 8); R(false, true, false, 16); R(false, true, false, 24);
     R(false, true, false, 31); R(false, true, false, 32);
     return 0;

@@ -32,7 +32,11 @@
 constexpr size_t LDS_CONV4 = (size_t)4 * 2048 * 16 + (size_t)2 * 3 * 4 * 2 * 64 * 8;   // 131 072 + 24 576 B
 
 // ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads, 32 no MFMAs
-template <bool RESID, bool STATS, bool CSUM, int ABL = 0>
+// STG: who stages the planes.  0: every wave two positions, the two waves of a SIMD at different points of the plane.  1: only the four
+// border-row waves (oh = 0, 3: two of three kh, a third less matrix work than the inner-row wave they share a SIMD with), four positions
+// each, at the top of the plane — the HBM round trips land in their slack, and the inner-row waves have no HBM request in their queue
+// (conv1) or only the residual row's (conv2).
+template <bool RESID, bool STATS, bool CSUM, int ABL = 0, int STG = 1>
 __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
 {
     static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
@@ -60,15 +64,18 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
 #pragma unroll
         for (int i = 0; i < 4; ++i) gam[cb][i] = A.in_gamma[16 * cb + 4 * q4 + i], bet[cb][i] = A.in_beta[16 * cb + 4 * q4 + i];
 
-    // ---- plane staging: wave w brings in positions 2w, 2w+1 (x 2 channel blocks) of every plane ----
-    f32x4 pf[4];
+    // ---- plane staging: a staging wave brings in NPP consecutive positions (x 2 channel blocks) of every plane ----
+    constexpr int NPP = STG == 1 ? 4 : 2, NPF = 2 * NPP;
+    const bool border = oh == 0 || oh == 3;                               // (waves 0, 3, 5, 6)
+    const int pos0 = STG == 1 ? 4 * ((oh == 3 ? 1 : 0) + 2 * mt) : 2 * wave;   // first position this wave stages
+    f32x4 pf[NPF];
     float pm[2], pr[2];
     auto issue_prefetch = [&](int P) __attribute__((always_inline)) {
         const int hh = (int)blockIdx.x + (P >> 2) * (int)gridDim.x, id = P & 3;
         const int tile = hh >> 1, jj = j16 + 16 * (hh & 1);
         const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 64 * 8 * 32 + 16 * (hh & 1));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pf[k] = buf_ld16(inb, lane_b + (k & 1) * 2048, (unsigned)(id * 16 + 2 * wave + (k >> 1)) * 4096u);
+        for (int k = 0; k < NPF; ++k) pf[k] = buf_ld16(inb, lane_b + (k & 1) * 2048, (unsigned)(id * 16 + pos0 + (k >> 1)) * 4096u);
         // GroupNorm(8,32): the group of quad 4cb + q4 is the quad itself.  The statistics change with the half tile only, but they travel with
         // EVERY plane: a load inside a branch makes the compiler count the loads in flight for the worse of the two paths, and every
         // fragment wait of the plane would then also wait for part of this HBM prefetch
@@ -89,14 +96,14 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
         }
         f32x4* dst = slots + (P & 3) * 2048 + q4 * 16 + j16;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NPF; ++k) {
             const int cb = k & 1;
             f32x4 v = pf[k];
             v.x = fmaxf(__builtin_fmaf(v.x, ia[cb][0], ib[cb][0]), 0.0f);
             v.y = fmaxf(__builtin_fmaf(v.y, ia[cb][1], ib[cb][1]), 0.0f);
             v.z = fmaxf(__builtin_fmaf(v.z, ia[cb][2], ib[cb][2]), 0.0f);
             v.w = fmaxf(__builtin_fmaf(v.w, ia[cb][3], ib[cb][3]), 0.0f);
-            dst[((2 * wave + (k >> 1)) * 8 + 4 * cb) * 16] = v;
+            dst[((pos0 + (k >> 1)) * 8 + 4 * cb) * 16] = v;
         }
     };
 
@@ -198,13 +205,15 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
     };
 
     // ---- prologue: planes 0 and 1 into their slots, plane 2 in flight ----
-    issue_prefetch(0);
-    write_plane(0);
-    if (NPL > 1) {
-        issue_prefetch(1);
-        write_plane(1);
+    if (STG == 0 || border) {
+        issue_prefetch(0);
+        write_plane(0);
+        if (NPL > 1) {
+            issue_prefetch(1);
+            write_plane(1);
+        }
+        if (NPL > 2) issue_prefetch(2);
     }
-    if (NPL > 2) issue_prefetch(2);
     lds_barrier();           // planes 0 and 1 are visible
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) ld_a(kw);      // plane 0 (od = 0): kd starts at 1
@@ -214,8 +223,8 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
     // The persistent plane loop exists twice, once per staging point (see `stage` below): with both copies of the plane body inside ONE loop the
     // compiler reconciles the operand registers of the two paths by copying all 56 of them at every plane boundary — behind a wait for
     // the next plane's operands, requested on purpose one step early.
-    auto run = [&](auto EARLY_C) __attribute__((always_inline)) {
-    constexpr bool EARLY = decltype(EARLY_C)::value;
+    auto run = [&](auto ROLE_C) __attribute__((always_inline)) {
+    constexpr bool ROLE = decltype(ROLE_C)::value;   // STG 0: stages after the plane's first step (else after its third); STG 1: stages at all
     for (int P = 0; P < NPL; ++P) {
         const int hh = (int)blockIdx.x + (P >> 2) * (int)gridDim.x, od = P & 3;
         const int tile = hh >> 1;
@@ -229,23 +238,31 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
         for (int ow = 0; ow < 4; ++ow) acc[ow] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         // Staging of plane P+2 (registers -> GroupNorm + ReLU -> LDS) and the HBM requests for plane P+3 (index clamped) and the residual
         // row.  Vector-memory operations return IN ORDER: the first operand wait behind these requests also waits for their HBM round trip.
-        // So (i) they go out between two steps, never at the top of the plane (where the wait for the staged registers would also sit
-        // behind the previous epilogue's stores); (ii) the two waves of a SIMD (w, w+4) do it at DIFFERENT points of the plane — one
-        // wave's stall is the other's matrix time; (iii) as two straight-line copies of the plane body, not as a branch inside it.
+        // The persistent loop exists once per role (straight-line code each: a request inside a branch would make the compiler count the
+        // operations in flight for the worse path and turn every operand wait into vmcnt(0); two roles inside one loop make it copy all
+        // 56 operand registers at every plane boundary).
         auto stage = [&]() __attribute__((always_inline)) {
             if (ABL & 4) return;
             if (P + 2 < NPL) write_plane(P + 2);   // (LDS stores only)
             issue_prefetch(P + 3 < NPL ? P + 3 : NPL - 1);
+        };
+        auto residual = [&]() __attribute__((always_inline)) {
             if (RESID) {
 #pragma unroll
                 for (int ow = 0; ow < 4; ++ow) sk[ow] = buf_ld16(skb, lane_b + mt * 2048, (unsigned)((od * 4 + oh) * 4 + ow) * 4096u);
             }
         };
-        step();
-        if (EARLY) stage();
-        step(), step();                  // (every plane has at least four steps)
-        if (!EARLY) stage();
-        for (int st = 3; st < ns; ++st) step();
+        if (STG == 1) {
+            if (ROLE) stage();
+            residual();
+            for (int st = 0; st < ns; ++st) step();
+        } else {
+            step();
+            if (ROLE) stage(), residual();
+            step(), step();                  // (every plane has at least four steps)
+            if (!ROLE) stage(), residual();
+            for (int st = 3; st < ns; ++st) step();
+        }
         // ---- epilogue: the row's 4 positions, ascending ----
         const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * 64 * 8 * 32 + 16 * (hh & 1));
         GnAcc st;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
         }
     }
     };
-    if (mt == 0) run(std::true_type{});
+    if (STG == 1 ? border : mt == 0) run(std::true_type{});
     else run(std::false_type{});
     if (STATS || CSUM) {
         lds_barrier();

@@ -1,0 +1,239 @@
+// vq_convdown_lds.h — the encoder's down conv, Conv3d(16->32,k4,s2,p1) 8^3 -> 4^3 (VQVAE_v2.py:239), with the INPUT PLANES streamed
+// through LDS exactly once (round 4).
+//
+// conv_rows16_k (weights LDS-resident, 128 KB) gives every wave a half tile and walks (output row, (kd,kh)) steps: each of the 64
+// input rows of a leaf is loaded 3.06 times, every re-load a miss (L2 hit rate 0.08, 6.6 GB fetched per 65 536-leaf launch for a
+// 2.15 GB input: profiles/r03_v3_pmc_l2_hit_miss.txt).  Here the INPUT planes are the outer loop.  Input plane id feeds exactly two
+// output planes: od_a = (id+1)/2 with kd = (id+1)%2 and od_b = od_a - 1 with kd + 2.  A workgroup of 8 waves owns a 16-leaf half tile;
+// wave = (parity g of the output planes it owns, output row oh): per input plane it has ONE (od, kd) to do — od of parity g among
+// {od_a, od_b} — and keeps that row's accumulators (4 positions x 2 cout tiles) over the four input planes 2od-1 .. 2od+2 that feed
+// it, so kd arrives ascending.  The planes travel global -> registers -> LDS once (two slots of 64 KB, plane Q in slot Q & 1, the
+// next plane written while this one is read; one barrier per input plane; the stream runs across half-tile boundaries), the weights
+// (128 KB, the same for every workgroup: L1 / L2 hits) come straight from global memory as MFMA A fragments.
+//
+// One step = (kd, kh): input row ih = 2 oh - 1 + kh (8 positions, LDS) and the 4 kw x 2 cout-tile fragments; 14 (ow, kw) pairs
+// (iw = 2 ow - 1 + kw inside the row) x 8 MFMAs, kw-major, the two cout tiles of a pair alternating; every operand is re-requested
+// for the next step right after its last use.  Per output the taps arrive in ascending (kd, kh, kw) order, the 16 channels of a tap
+// in "P16" order: conv_rows16_k's arithmetic and the oracle's, bit for bit.  Border rows (oh = 0, 3: three of four kh) share a
+// SIMD with inner rows.
+//
+// Statistics of the output (GroupNorm(8,32) of the residual block that follows): one output row = one block of the 16-block
+// contract; a wave keeps its two rows' block sums, all waves pass them through LDS at the end of the half tile and wave 0 adds the
+// sixteen in block order after the next barrier.
+#pragma once
+#include "vq_conv8_lds.h"
+
+constexpr size_t LDS_CONVDOWN = (size_t)2 * 4096 * 16 + (size_t)8 * 2 * 2 * 2 * 64 * 8;   // 131 072 + 32 768 B = all 160 KB
+
+// ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
+{
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* slots = (f32x4*)smem_raw;                                    // [2][64 pos][4 quads][16 leaves]
+    double* xch = (double*)(smem_raw + (size_t)2 * 4096 * 16);          // [wave 8][row 2][mt 2][2][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, j16 = lane & 15;
+    // waves w and w+4 share a SIMD: (g, oh) = (0, w) and (1, perm(w-4)), perm = 1,0,3,2 -> one border and one inner row per SIMD
+    const int g = wave >> 2, oh = g ? ((wave & 3) ^ 1) : wave;
+    const int k0 = oh == 0 ? 1 : 0, nk = (oh == 0 || oh == 3) ? 3 : 4;   // valid kh (ih = 2 oh - 1 + kh in 0..7): k0 .. k0 + nk - 1
+    const int n_half = 2 * A.n_tiles;
+    if ((int)blockIdx.x >= n_half) return;
+    const int n_my = (n_half - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int NPL = n_my * 8;                                             // input planes this workgroup walks
+    const unsigned lane_b = (unsigned)(q4 * 32 + j16) * 16u;
+    const f32x4 bias4[2] = {((const f32x4*)A.bias_frag)[q4], ((const f32x4*)A.bias_frag)[4 + q4]};
+    const vq_buf wb = buf_of(A.wfrag);
+    const unsigned lane_w = (unsigned)lane * 16u;
+
+    // ---- plane staging: wave w brings in input row ih = w (8 positions) of every plane: a plain copy, the input is raw ----
+    f32x4 pf[8];
+    auto issue_prefetch = [&](int Q) __attribute__((always_inline)) {
+        const int hh = (int)blockIdx.x + (Q >> 3) * (int)gridDim.x, id = Q & 7;
+        const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)(hh >> 1) * 512 * 4 * 32 + 16 * (hh & 1));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pf[k] = buf_ld16(inb, lane_b, (unsigned)(id * 64 + wave * 8 + k) * 2048u);
+    };
+    auto write_plane = [&](int Q) __attribute__((always_inline)) {
+        f32x4* dst = slots + (Q & 1) * 4096 + ((wave * 8) * 4 + q4) * 16 + j16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k * 4 * 16] = pf[k];
+    };
+
+    // which (od, kd) of this wave input plane id feeds: od of parity g among od_a = (id+1)/2 (kd = (id+1)%2) and od_a - 1 (kd + 2)
+    auto od_of = [&](int id) { const int oa = (id + 1) >> 1; return (oa & 1) == g ? oa : oa - 1; };
+    auto kd_of = [&](int id) { const int oa = (id + 1) >> 1; return ((id + 1) & 1) + ((oa & 1) == g ? 0 : 2); };
+    auto works = [&](int id) { const int o = od_of(id); return o >= 0 && o <= 3; };
+
+    f32x4 acc[4][2];
+    // Operands of one (kd, kh) step: a[kw][mt] = A fragments of taps (kd*4 + kh)*4 + kw (global memory: L1 / L2 hits), x[iw] = the 8
+    // positions of input row ih = 2 oh - 1 + kh of the plane (LDS).  One register set; every operand is re-requested for the next step
+    // of the stream (this plane's next kh, else the first kh of this wave's next working plane) right after its last MFMA.  Requests
+    // are unconditional.  The LDS re-requests at a plane's last step read a slot that is still being written: they are repeated
+    // after the barrier (x_all), the early copy is never used.
+    f32x4 a[4][2], x[8];
+    int rq = 0, ri = 0;                 // the step being requested: input plane, kh - k0
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++ri == nk) {
+            ri = 0;
+            ++rq;
+            if (!works(rq & 7)) ++rq;   // (a wave idles at id = 0 (g = 1) or id = 7 (g = 0): never two planes in a row)
+        }
+    };
+    auto ld_a = [&](int kw) __attribute__((always_inline)) {
+        const unsigned t = (unsigned)((kd_of(rq & 7) * 4 + k0 + ri) * 4 + kw);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[kw][mt] = (ABL & 16) ? bias4[mt] : buf_ld16(wb, lane_w, (t * 2 + mt) * 1024u);
+    };
+    auto ld_x = [&](int iw) __attribute__((always_inline)) {
+        x[iw] = (ABL & 8) ? bias4[0] : slots[(rq & 1) * 4096 + (((2 * oh - 1 + k0 + ri) * 8 + iw) * 4 + q4) * 16 + j16];
+    };
+    // one (ow, kw) pair: 8 MFMAs, k outer, the two cout tiles alternating (independent accumulators)
+    auto pair = [&](int ow, int kw) __attribute__((always_inline)) {
+        const int iw = 2 * ow - 1 + kw;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[ow][mt] = mfma16(a[kw][mt][k], x[iw][k], acc[ow][mt]);
+    };
+    // kw-major: kw 0: ow 1,2,3 | kw 1: ow 0..3 | kw 2: ow 0..3 | kw 3: ow 0,1,2 — every accumulator sees its kw ascending.  Last uses:
+    // a[0] after (3,0), a[1] after (3,1), a[2] after (3,2), a[3] after (2,3); x1 (0,2), x3 (1,2), x5 (2,2), x7 (3,2), x0 (0,1), x2 (0,3),
+    // x4 (1,3), x6 (2,3): every re-request is at least six pairs (1.5 k cycles) ahead of its first use in the next step.
+    auto step = [&]() __attribute__((always_inline)) {
+        advance();   // (rq, ri): the NEXT step — what the re-requests below fetch
+        pair(1, 0), pair(2, 0), pair(3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(0);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_x(0);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(1, 1), pair(2, 1), pair(3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_x(1);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_x(3);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_x(5);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(3, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(2);
+        ld_x(7);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_x(2);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_x(4);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(2, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(3);
+        ld_x(6);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // block sums of this wave's two rows (od = g, g + 2) of the current half tile, per cout tile
+    double bs[2][2], bq[2][2];
+    auto finish_stats = [&](int hh) __attribute__((always_inline)) {   // wave 0: the sixteen blocks of half tile hh in block order
+        if (wave != 0) return;
+        const int tile = hh >> 1, jj = j16 + 16 * (hh & 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            double S = 0.0, Q = 0.0;
+#pragma unroll
+            for (int blk = 0; blk < 16; ++blk) {
+                const int o = blk & 3, d = blk >> 2;                  // block = output row (od = d, oh = o)
+                const int wv = (d & 1) ? 4 + (o ^ 1) : o;              // its wave: g = d & 1, oh = o
+                S += xch[(((wv * 2 + (d >> 1)) * 2 + mt) * 2 + 0) * 64 + lane];
+                Q += xch[(((wv * 2 + (d >> 1)) * 2 + mt) * 2 + 1) * 64 + lane];
+            }
+            float m, r;
+            gn_finish(S, Q, 1.0 / 256.0, m, r);   // GroupNorm(8,32): 4 channels x 64 positions
+            A.out_mean[((size_t)tile * 8 + 4 * mt + q4) * 32 + jj] = m;
+            A.out_rstd[((size_t)tile * 8 + 4 * mt + q4) * 32 + jj] = r;
+        }
+    };
+
+    // ---- prologue: plane 0 into slot 0, plane 1 in flight; the first step's operands ----
+    issue_prefetch(0);
+    write_plane(0);
+    if (NPL > 1) issue_prefetch(1);
+    rq = works(0) ? 0 : 1;
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) ld_a(kw);
+
+    for (int Q = 0; Q < NPL; ++Q) {
+        const int hh = (int)blockIdx.x + (Q >> 3) * (int)gridDim.x, id = Q & 7;
+        const int tile = hh >> 1;
+        // every wave is done with plane Q-1 (its slot is free) and plane Q, written during plane Q-1, is visible
+        if (!(ABL & 1)) lds_barrier();
+        if (id == 0 && Q > 0) finish_stats(hh - (int)gridDim.x);
+        if (!(ABL & 4)) {
+            if (Q + 1 < NPL) write_plane(Q + 1);
+            issue_prefetch(Q + 2 < NPL ? Q + 2 : NPL - 1);
+        }
+        if (!works(id)) continue;   // (wave-uniform)
+        const int od = od_of(id), kd = kd_of(id);
+        if (kd == 0 || (od == 0 && kd == 1)) {   // first plane of this output row
+#pragma unroll
+            for (int ow = 0; ow < 4; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int iw = 0; iw < 8; ++iw) ld_x(iw);   // (rq, ri) = this plane's first step: its plane became visible at the barrier
+        for (int st = 0; st < nk; ++st) step();
+        if (!(kd == 3 || (od == 3 && kd == 2))) continue;   // the row is complete after its last plane
+        // ---- epilogue: the row's 4 positions, ascending; the two cout tiles ----
+        const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * 64 * 8 * 32 + 16 * (hh & 1));
+        GnAcc st[2];
+        st[0].init(), st[1].init();
+        if (!(ABL & 2)) {
+#pragma unroll
+            for (int ow = 0; ow < 4; ++ow)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f32x4 v = acc[ow][mt] + bias4[mt];
+                    buf_st16_nt(v, outb, lane_b + mt * 2048, (unsigned)((od * 4 + oh) * 4 + ow) * 4096u);
+                    st[mt].add(v.x);
+                    st[mt].add(v.y);
+                    st[mt].add(v.z);
+                    st[mt].add(v.w);
+                }
+        } else {
+            float t = 0.0f;
+#pragma unroll
+            for (int ow = 0; ow < 4; ++ow) t += acc[ow][0].x + acc[ow][1].w;
+            if (t == 12345.678f) ((f32x4*)A.out)[tid] = acc[0][0];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (od >> 1) bs[1][mt] = st[mt].bs, bq[1][mt] = st[mt].bq;
+            else bs[0][mt] = st[mt].bs, bq[0][mt] = st[mt].bq;
+        }
+        if (od >> 1) {   // this wave's second row: both of its blocks go to LDS (read by wave 0 after the next barrier)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    xch[(((wave * 2 + r) * 2 + mt) * 2 + 0) * 64 + lane] = bs[r][mt];
+                    xch[(((wave * 2 + r) * 2 + mt) * 2 + 1) * 64 + lane] = bq[r][mt];
+                }
+        }
+    }
+    lds_barrier();
+    finish_stats((int)blockIdx.x + (n_my - 1) * (int)gridDim.x);
+}

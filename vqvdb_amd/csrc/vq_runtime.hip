@@ -29,6 +29,7 @@
 #include "vq_conv8_lds.h"
 #include "vq_stem_taps.h"
 #include "vq_conv4_lds.h"
+#include "vq_convdown_lds.h"
 #include "vq_train_kernels.h"
 #include "vq_grad_kernels.h"
 #include "vq_train_tail.h"
@@ -162,6 +163,7 @@ struct vqhip_codec {
     bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
     int vq_split = 2;        // position ranges per tile in the VQ search of full chunks (VQHIP_VQ_SPLIT)
     bool conv8_w16 = true;   // ... with 16 waves (one half row each; a half row is a statistics block); VQHIP_CONV8=w8 selects 8 (one row each)
+    bool convdown_lds = true;   // down conv of large passes: input planes streamed through LDS once, weights from L1 / L2 (vq_convdown_lds.h); VQHIP_DOWN=rows selects the row kernel (input re-fetched 3.06x)
     bool conv4_lds = true;   // 32-channel 4^3 convs of large passes: input planes in an LDS ring, weights straight from L1 / L2 (vq_conv4_lds.h); VQHIP_CONV4=rows selects the row kernel (weights LDS-resident, every input row re-fetched 6.25x)
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
@@ -947,8 +949,9 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, conv8_lds_k<true, false, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, k_stem_taps, LDS_STEM_TAPS))) return rc;
-    if ((rc = set_lds(c, conv4_lds_k<false, true, false>, LDS_CONV4))) return rc;
-    if ((rc = set_lds(c, conv4_lds_k<true, false, true>, LDS_CONV4))) return rc;
+    if ((rc = set_lds(c, conv_down_lds_k<0>, LDS_CONVDOWN))) return rc;
+    if ((rc = set_lds(c, conv4_lds_k<false, true, false, 0, 1>, LDS_CONV4))) return rc;
+    if ((rc = set_lds(c, conv4_lds_k<true, false, true, 0, 0>, LDS_CONV4))) return rc;
     if ((rc = set_lds(c, latent_assign_k<8>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<2>, LDS_LATENT))) return rc;
     if ((rc = set_lds(c, latent_assign_k<4>, LDS_LATENT))) return rc;
@@ -1185,7 +1188,8 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"];
         A.out_mean = S.x7m, A.out_rstd = S.x7r, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64;
-        L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
+        if (c->convdown_lds) L.run("enc_down", [&] { hipLaunchKernelGGL(conv_down_lds_k<0>, dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONVDOWN, s, A); });
+        else L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
     }
     {
         ConvArgs A{};
@@ -1193,7 +1197,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in_mean = S.x7m, A.in_rstd = S.x7r, A.in_gamma = w["r32g1.w"], A.in_beta = w["r32g1.b"];
         A.out_mean = S.y9m, A.out_rstd = S.y9r, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
-        if (c->conv4_lds) L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL((conv4_lds_k<false, true, false>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV4, s, A); });
+        if (c->conv4_lds) L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL((conv4_lds_k<false, true, false, 0, 1>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV4, s, A); });
         else L.run("enc_res32_conv1", [&] { hipLaunchKernelGGL(k_enc_r32c1_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
     {
@@ -1202,7 +1206,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in_mean = S.y9m, A.in_rstd = S.y9r, A.in_gamma = w["r32g2.w"], A.in_beta = w["r32g2.b"];
         A.out_csum = S.csum, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k3_4"], A.n_taps = 27;
-        if (c->conv4_lds) L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL((conv4_lds_k<true, false, true>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV4, s, A); });
+        if (c->conv4_lds) L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL((conv4_lds_k<true, false, true, 0, 0>), dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONV4, s, A); });
         else L.run("enc_res32_conv2", [&] { hipLaunchKernelGGL(k_enc_r32c2_r, dim3((2 * nt + 15) / 16), dim3(1024), LDS_ENC_R32R, s, A, (const int4*)w["steps.rows_k3_4"]); });
     }
 
@@ -1699,6 +1703,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
         return bail(VQHIP_ERR_DEVICE);
     }
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = std::getenv("VQHIP_DOWN")) c->convdown_lds = std::strcmp(e, "rows") != 0;
     if (const char* e = std::getenv("VQHIP_CONV4")) c->conv4_lds = std::strcmp(e, "rows") != 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
