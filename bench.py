@@ -108,7 +108,7 @@ def train_step_classes(codec, step_fn, leaves, device, steps=3):
         n = st["name"]
         cls = "wgrad" if "_wgrad" in n else "dgrad" if "_dgrad" in n else "forward" if n.startswith(fwd) and n != "ft_tail_fold" else "other"
         ms[cls] += st["total_ms"] / steps
-    out = {"kernel_time_ms_per_step": round(sum(ms.values()), 4)}
+    out = {"summed_event_spans_ms_per_step": round(sum(ms.values()), 4)}   # (two streams: the spans overlap; not a wall time)
     for cls, t in ms.items():
         e = {"ms": round(t, 4)}
         if cls in TRAIN_ISSUED_FLOP and t > 0:
@@ -407,7 +407,7 @@ def main():
             from vqvdb_amd.full_training import FullTrainer
             fcodec = HipCodec(weightpack.dumps(W), device_id=dev_index)
             ftr = FullTrainer(fcodec, device=str(device))
-            full = {"note": "one optimizer step = training-mode forward (unfolded decoder) + backward of every layer + all-reduce + AdamW + EMA "
+            full = {"note": "one optimizer step = training-mode forward (decoder stem through the per-step (tap, code) table, decoder tail folded) + backward of every layer + all-reduce + AdamW + EMA "
                             "codebook update + rebuild of the weight-derived tables, fp32; not the headline value",
                     "collective": coll("995905 + 33284"),
                     "flop_per_leaf_nominal": 3 * (ENC_FLOP + DEC_FLOP), "flop_per_leaf_issued": TRAIN_ISSUED_FLOP,
@@ -417,7 +417,7 @@ def main():
                                  "algebraic eliminations buy, not a utilisation (it exceeds 1 at 8192 leaves per rank)",
                     "streams": 1 if os.environ.get("VQHIP_TRAIN_STREAMS") == "1" else 2,
                     "streams_note": "weight / bias gradients run on a second stream beside the data-gradient chain: by_class times are event spans on "
-                                    "either stream, they overlap, and kernel_time_ms_per_step exceeds ms_per_step; whole_step_frac (from the wall time) "
+                                    "either stream, they overlap, and summed_event_spans_ms_per_step exceeds ms_per_step; whole_step_frac (from the wall time) "
                                     "is the utilisation of the step"}
             ksteps = max(2, min(args.steps, 6))
             for per_rank_b in (2048, 8192):

@@ -148,7 +148,8 @@ int vqhip_multi_decode(vqhip_multi* multi, const uint8_t* indices, int64_t n_lea
 
 /* Leaves processed per internal pass (default 65536).  Bounds the device workspace
  * (about 0.1 MB per leaf for inference: three shared 32 KiB-per-leaf activation regions; 0.24 MB per leaf while
- * debug mode or the training entry points keep every intermediate).  If the device has less free memory than the chunk
+ * debug mode keeps every intermediate; the full training step adds its own workspace of 0.60 MB per leaf — saved
+ * activations and gradient buffers — sized for the training batch, not for the chunk).  If the device has less free memory than the chunk
  * needs (a GPU shared with a DCC application), the chunk is halved until workspace + I/O slots fit into 80 % of the free memory:
  * once, at the first host-pointer call (or vqhip_reserve) of the handle, and again at the call after a workspace allocation has
  * failed with VQHIP_ERR_NOMEM (that call itself fails; the handle stays usable).  Results never depend on the chunk size. */

@@ -29,6 +29,7 @@ LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the lib
     (r"conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true[,>]", "enc_down"),
     (r"conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true[,>]", "enc_res32_conv1"),
     (r"conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true[,>]", "enc_res32_conv2"),
+    (r"conv_down_lds_k", "enc_down"), (r"conv4_lds_k<false, true, false", "enc_res32_conv1"), (r"conv4_lds_k<true, false, true", "enc_res32_conv2"),   # round 4: LDS plane rings
     (r"vq_folded_k<8>", "enc_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
     (r"gn_relu_stats_k<64", "dec_gn_relu_stats"), (r"stem_fused_k", "dec_stem_gn"), (r"stem_taps_k", "dec_stem_gn"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false[,>]", "dec_res64_conv1"),
@@ -45,7 +46,7 @@ def read(path, counter):
     # max, not avg: a persistent kernel (grid = CUs) has the same grid for its 65536-leaf launches and for mid-size passes
     for name, grid, gy, avg in db.execute("select kernel_name, grid_size_x, grid_size_y, max(value) from counters_collection where counter_name=? "
                                           "group by kernel_name, grid_size_x, grid_size_y", (counter,)):
-        if gy != 1:   # position-split launches (small batches)
+        if gy != 1 and not (gy == 2 and "vq_folded_k<8>" in name):   # position-split launches (small batches); the full-chunk VQ search runs two position ranges per tile
             continue
         for rx, launch in LAUNCH:
             if re.search(rx, name) and not name.startswith("build_") and grid > best.get(launch, -1):

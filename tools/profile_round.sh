@@ -19,7 +19,7 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum -d $OUT/pmc_tc
 find $OUT -name "*.db" | xargs ls -la
 cat $OUT/bench.json | head -c 600
 # summaries (small text / json files for profiles/); the databases themselves stay on the box
-TAG=${PROFILE_TAG:-r03_v3}
+TAG=${PROFILE_TAG:-r04_v1}
 SUM=$R/gpurun_out/prof_sum; mkdir -p $SUM
 python $R/tools/rocpd_summary.py --kt $OUT/kt/r02_results.db --fetch $OUT/pmc_fetch/r02_results.db --write $OUT/pmc_write/r02_results.db > $SUM/${TAG}_bench_rocprofv3_summary.txt
 python $R/tools/pmc_sq_summary.py $OUT/pmc_sq/r02_results.db > $SUM/${TAG}_pmc_mfma_util_clock.txt

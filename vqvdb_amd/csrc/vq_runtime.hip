@@ -54,6 +54,7 @@ struct NameMap {
         std::string first;
         T second;
     };
+    static constexpr size_t kMaxNames = 1024;   // (the largest table, the device-buffer names of a training handle, holds ~250)
     std::vector<Ent> ents;
     std::vector<int> slots;   // index into ents, -1 = empty; size is a power of two > 2 * ents.size()
     static uint32_t hash(const char* s)
@@ -87,6 +88,13 @@ struct NameMap {
     {
         int e = lookup(s);
         if (e < 0) {
+            // references handed out by operator[] must stay valid across later insertions (callers hold `auto& w = c->dw` and lambdas capture
+            // it): the entries live in storage reserved once; a table that outgrows it is a programming error and stops loudly
+            if (ents.capacity() == 0) ents.reserve(kMaxNames);
+            if (ents.size() == ents.capacity()) {
+                fprintf(stderr, "vqvdb_hip: NameMap overflow (%zu names) at '%s'\n", ents.size(), s);
+                abort();
+            }
             ents.push_back(Ent{s, T()});
             e = (int)ents.size() - 1;
             if (slots.size() < 4 * ents.size()) rehash();
