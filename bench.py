@@ -133,6 +133,26 @@ def hbm_traffic(kernel):
         return None
 
 
+# bytes per leaf a layer reads + writes when every tensor crosses HBM exactly once (fp32, leaf-tile layout): input (+ residual input) + output
+LAYER_IO_BYTES = {"pack_leaves": 2048 + 3072, "enc_conv_first_stats": 3072, "enc_conv_first_gn": 3072 + 32768, "enc_res16_conv1": 2 * 32768, "enc_res16_conv2": 3 * 32768,
+                  "enc_down": 32768 + 8192, "enc_res32_conv1": 2 * 8192, "enc_res32_conv2": 3 * 8192, "enc_vq": 8192 + 64,
+                  "dec_stem_gn": 64 + 16384, "dec_res64_conv1": 2 * 16384, "dec_res64_conv2": 3 * 16384, "dec_tail": 16384 + 2048}
+ALGORITHMIC_BYTES = 2048 + 64      # per leaf, either direction: the leaf and its 64 indices
+
+
+def path_traffic(kernels):
+    """HBM bytes per 65536-leaf pass summed over the pass's kernels (committed PMC table), None when a kernel is missing from the table."""
+    tot = 0
+    for k in kernels:
+        t = hbm_traffic(k["kernel"])
+        if t is None:
+            if k["kernel"] in LAYER_IO_BYTES:
+                return None
+            continue      # (statistics-combine launches: a few hundred KB)
+        tot += t["bytes"]
+    return tot
+
+
 def roofline_of(kernels, nominal_flop_per_leaf, leaves_per_s_per_gpu):
     """Roofline of the dominant kernel (longest average launch).  `achieved`/`frac` count the FLOPs the kernel ISSUES on the
     matrix pipe (zero-padding taps are skipped, folded operators counted at their folded cost) — a true utilisation, <= 1, that
@@ -140,9 +160,18 @@ def roofline_of(kernels, nominal_flop_per_leaf, leaves_per_s_per_gpu):
     kernel replaces is reported beside it as *_nominal_dense; it can exceed the peak and is not a utilisation."""
     dom = max(kernels, key=lambda k: k["avg_ms"])
     issued_per_leaf = sum(k["issued_flop_per_leaf"] for k in kernels)
+    tr = hbm_traffic(dom["kernel"])
+    ptr = path_traffic(kernels)
     return {
+        # flat copies of the traffic figures (a summariser that drops nested objects keeps these): the dominant kernel's HBM bytes per launch
+        # against its layer's tensors crossing HBM once, and the whole pass against the algorithmic 2112 B per leaf
+        "traffic_bytes": tr["bytes"] if tr else None,
+        "traffic_over_layer_io": round(tr["bytes"] / (LAYER_IO_BYTES[dom["kernel"]] * BATCH), 3) if tr and dom["kernel"] in LAYER_IO_BYTES else None,
+        "traffic_stale": tr["stale"] if tr else None,
+        "whole_path_traffic_bytes": ptr,
+        "whole_path_traffic_over_algorithmic": round(ptr / (ALGORITHMIC_BYTES * BATCH), 1) if ptr else None,
         "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops_issued"], "peak": PEAK_TF, "unit": "TFLOP/s",
-        "frac": round(dom["tflops_issued"] / PEAK_TF, 4), "traffic": hbm_traffic(dom["kernel"]),
+        "frac": round(dom["tflops_issued"] / PEAK_TF, 4), "traffic": tr,
         "avg_launch_ms": dom["avg_ms"], "flop_per_launch_issued": dom["issued_flop_per_leaf"] * BATCH,
         "achieved_nominal_dense": dom["tflops_nominal_dense"], "ratio_nominal_dense_to_peak": round(dom["tflops_nominal_dense"] / PEAK_TF, 4),
         "whole_path_frac": round(leaves_per_s_per_gpu * issued_per_leaf / (PEAK_TF * 1e12), 4),

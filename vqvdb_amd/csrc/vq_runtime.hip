@@ -898,7 +898,7 @@ int set_lds(vqhip_codec* c, K kernel, size_t bytes)
 //                                        CIN COUT SI SO KS ST PD NW INMODE GIN RESID GOUT CSUM
 // decoder front of full chunks: gathers row by row (PIPE 0: the tap loop is bound by the LDS itself, reads in flight ahead bought nothing),
 // the two position halves of a leaf octet on one SIMD (HMAP 1), the first taps of a pass not waiting for the previous pass's stores (RELAX)
-constexpr auto k_stem_taps = stem_taps_k<0, 1, 0, true, 0>;
+constexpr auto k_stem_taps = stem_taps_k<0, 1, 0, true, 0, true>;   // (+ checkerboard row ownership: equal valid rows per wave in every tap)
 constexpr auto k_dec_tail = conv_mfma32_k<64, 128, 64, 4, 8, true, 1, 2, 0, false, 0, false, 2>;  // folded up_conv+pixshuf+final
 //                                           CIN COUT SI SO KS ST PD INMODE RESID GOUT CSUM
 // large passes: kw-outer MFMA order (A fragments of a (kw, channel-block pair) read once for every output of the row)

@@ -53,8 +53,11 @@ __device__ __forceinline__ void lds_frags_wait_n() { asm volatile("s_waitcnt lgk
 // younger than those slices in the wave's vector-memory queue: vmcnt counts in order).  STAG: workgroups start in four groups
 // STAG x 4096 cycles apart, so that the 256 KB output bursts of the chip's 256 workgroups — every pass ends with one, and the passes
 // of a persistent launch are equally long, i.e. stay in lockstep — do not hit HBM at the same moment.
+// CHK: which 32 of the tile's 64 positions a wave owns.  false: a position half (planes 2h, 2h+1) — for kd = 0 and kd = 2 one half then has
+// half the valid rows of the other, and the per-tap barrier makes the lighter waves wait (no barrier: 0.57 -> 0.49 ms).  true: the rows
+// (od, oh) with (od + oh) % 2 == h, a checkerboard over the 16 rows: both waves of an octet have 4-5 or 6 or 8 valid rows in every tap.
 // ABL (tools/ablate only): 1 no gather reads, 2 no adds, 4 no table DMA, 8 no epilogue, 16 no per-tap barrier, 32 no output stores.
-template <int PIPE = 0, int HMAP = 0, int ABL = 0, bool RELAX = false, int STAG = 0>
+template <int PIPE = 0, int HMAP = 0, int ABL = 0, bool RELAX = false, int STAG = 0, bool CHK = false>
 __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
 {
     static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
@@ -69,7 +72,10 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
     const int oct = HMAP ? (wave & 3) : (wave >> 1), h = HMAP ? (wave >> 2) : (wave & 1);
     const int l = lane >> 3, c = lane & 7;
     const int jt = 8 * oct + l;                                       // leaf of this lane in the tile
-    const unsigned nb_addr = sidx_off + (unsigned)(jt * 128 + 32 + 32 * h);
+    const unsigned nb_addr = sidx_off + (unsigned)(jt * 128 + 32 + (CHK ? 0 : 32 * h));
+    // row r = 0..7 of this wave -> (od, oh).  CHK: od = r / 2, oh = 2 (r % 2) + (od + h) % 2 (h is wave-uniform: scalar arithmetic)
+    auto od_of = [&](int r) { return CHK ? (r >> 1) : 2 * h + (r >> 2); };
+    auto oh_of = [&](int r) { return CHK ? 2 * (r & 1) + (((r >> 1) + h) & 1) : (r & 3); };
     double* xq = xch + ((size_t)oct * 64 + lane) * 2;
     // slice (t, half) -> slot: DMA instruction i of a slice covers codes 8i .. 8i+7 (lane = (code, chunk)); wave w issues i = w, w+8, w+16, w+24.
     // Buffer addressing: descriptor in SGPRs, one constant per-lane offset, the rest wave-uniform (a per-lane 64-bit pointer per piece
@@ -118,11 +124,11 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                 {
                     const unsigned a0 = nb_addr + (unsigned)((kd - 1) * 16 + (kh - 1) * 4);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) nb[r] = lds_u32_read(a0 + 4u * r);
+                    for (int r = 0; r < 8; ++r) nb[r] = lds_u32_read(a0 + (CHK ? (unsigned)(16 * od_of(r) + 4 * oh_of(r)) : 4u * r));
                 }
                 bool rv[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) rv[r] = (unsigned)(2 * h + (r >> 2) + kd - 1) < 4u && (unsigned)((r & 3) + kh - 1) < 4u;
+                for (int r = 0; r < 8; ++r) rv[r] = (unsigned)(od_of(r) + kd - 1) < 4u && (unsigned)(oh_of(r) + kh - 1) < 4u;
                 auto tap = [&](auto KW) {   // kw as a compile-time constant: the reads per row (and the wait counts) depend on it
                     constexpr int kw = decltype(KW)::value;
                     const int t = kdkh * 3 + kw;
@@ -242,7 +248,31 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                 }
                 bs[r] = st.bs, bq[r] = st.bq;
             }
+            // the sixteen block sums (block = output row od*4 + oh) in block order.  Position halves: wave h = 0 holds blocks 0..7, h = 1 blocks
+            // 8..15 — a running total handed from one to the other.  Checkerboard: the owners alternate, so the h = 1 wave passes its eight
+            // sums through the ring's fourth slot (free until the next pass's tap 0 has passed its barrier) and the h = 0 wave adds all sixteen.
             auto ordered_totals = [&](double& S, double& Q) {
+                if (CHK) {
+                    double* sc = (double*)(ring + 3 * 2048) + (size_t)oct * 8 * 64 * 2 + lane;   // [oct][row 8][s | q][lane]
+                    if (h == 1) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) sc[(r * 2 + 0) * 64] = bs[r], sc[(r * 2 + 1) * 64] = bq[r];
+                    }
+                    __syncthreads();
+                    if (h == 0) {
+                        S = 0.0, Q = 0.0;
+#pragma unroll
+                        for (int b = 0; b < 16; ++b) {
+                            const int od = b >> 2, oh = b & 3, r = od * 2 + (oh >> 1);   // (static) the owner's row number
+                            if (((od + oh) & 1) == 0) S += bs[r], Q += bq[r];
+                            else S += sc[(r * 2 + 0) * 64], Q += sc[(r * 2 + 1) * 64];
+                        }
+                        xq[0] = S, xq[1] = Q;
+                    }
+                    __syncthreads();
+                    if (h == 1) S = xq[0], Q = xq[1];
+                    return;
+                }
                 if (h == 0) {
                     S = 0.0, Q = 0.0;
 #pragma unroll
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
 #pragma unroll
                     for (int pw = 0; pw < 4; ++pw) {
                         const f32x4 v = acc[4 * r + pw];
-                        const unsigned po = (unsigned)(32 * h + 4 * r + pw);
+                        const unsigned po = (unsigned)(16 * od_of(r) + 4 * oh_of(r) + pw);
                         if (A.ystem_dbg) buf_st16(v, dbgb, lane_o, po * 8192u);
                         f32x4 y;
                         y.x = fmaxf(__builtin_fmaf(v.x, ia[0], ib[0]), 0.0f);
