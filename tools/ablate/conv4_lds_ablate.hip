@@ -5,6 +5,7 @@
 #include <vector>
 #define VQ_ABLATE 1
 #include "vq_conv4_lds.h"
+#include "vq_convdown_lds.h"
 
 template <typename K>
 static float run(const char* name, K k, ConvArgs A, int grid, int threads, size_t lds)
@@ -59,5 +60,21 @@ int main()
     RS(false, true, false, 0); RS(true, false, true, 0); RS(false, true, false, 1); RS(true, false, true, 1); RS(false, true, false, 0); RS(true, false, true, 0);
     R(false, true, false, 1); R(false, true, false, 2); R(false, true, false, 4); R(false, true, false, 8); R(false, true, false, 16); R(false, true, false, 24);
     R(false, true, false, 31); R(false, true, false, 32);
+    {   // the down conv: 16 -> 32 k4 s2, input 8^3 x 16 channels (its own input buffer; outputs and statistics land in the 4^3 buffers: timing only)
+        float* wd;
+        hipMalloc(&wd, 64 * 2 * 64 * 16);
+        fill(wd, 64 * 2 * 64 * 4, 9, -0.1f, 0.1f);
+        hipDeviceSynchronize();
+        float* din;
+        const size_t dact = (size_t)nt * 512 * 16 * 32 * 4;     // 8^3 x 16 channels per leaf
+        hipMalloc(&din, dact);
+        fill(din, dact / 4, 10);
+        hipDeviceSynchronize();
+        ConvArgs D = A;
+        D.wfrag = wd, D.in = din;
+#define RD(ABL, TWOB) run("conv_down_lds_k ABL " #ABL " TWOB " #TWOB, conv_down_lds_k<ABL, TWOB>, D, cus, 512, LDS_CONVDOWN)
+#define RDS(S) run("conv_down_lds_k one barrier, staging at " #S, conv_down_lds_k<0, false, S>, D, cus, 512, LDS_CONVDOWN)
+        RDS(0); RDS(1); RD(0, true); RDS(0); RDS(1); RD(0, true); RD(1, false); RD(2, false); RD(4, false); RD(8, false); RD(16, false);
+    }
     return 0;
 }

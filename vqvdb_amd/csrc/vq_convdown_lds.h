@@ -26,7 +26,7 @@
 constexpr size_t LDS_CONVDOWN = (size_t)2 * 4096 * 16 + (size_t)8 * 2 * 2 * 2 * 64 * 8;   // 131 072 + 32 768 B = all 160 KB
 
 // ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads
-template <int ABL = 0>
+template <int ABL = 0, bool TWOB = false, int STAGE_AT = 1>
 __global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
 {
     static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
@@ -183,19 +183,33 @@ __global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
         // every wave is done with plane Q-1 (its slot is free) and plane Q, written during plane Q-1, is visible
         if (!(ABL & 1)) lds_barrier();
         if (id == 0 && Q > 0) finish_stats(hh - (int)gridDim.x);
-        if (!(ABL & 4)) {
+        // staging of plane Q+1 (registers -> LDS) and the requests for plane Q+2: at the top of the plane (STAGE_AT 0) or behind the wave's
+        // first step (1) — the wait for the staged registers is a vmcnt(0) (the number of younger requests varies), and at the top it also
+        // waits for the write acknowledgements of the epilogue that has just run
+        auto stage = [&]() __attribute__((always_inline)) {
+            if (ABL & 4) return;
             if (Q + 1 < NPL) write_plane(Q + 1);
             issue_prefetch(Q + 2 < NPL ? Q + 2 : NPL - 1);
-        }
+        };
+        if (STAGE_AT == 0 || TWOB || !works(id)) stage();
+        // a second barrier right behind the staging (the waves have just met: little skew): plane Q+1 is visible from HERE, so the last
+        // step of this plane can already request the first B operands of the next one
+        if (TWOB && !(ABL & 1)) lds_barrier();
         if (!works(id)) continue;   // (wave-uniform)
         const int od = od_of(id), kd = kd_of(id);
         if (kd == 0 || (od == 0 && kd == 1)) {   // first plane of this output row
 #pragma unroll
             for (int ow = 0; ow < 4; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
+        // (rq, ri) = this plane's first step.  One barrier per plane: its B operands can only be requested now (the early copy read a slot
+        // that was still being written).  Two: only behind a plane this wave sat out (the early copy was requested two planes ahead).
+        if (!TWOB || Q == 0 || !works((id + 7) & 7)) {
 #pragma unroll
-        for (int iw = 0; iw < 8; ++iw) ld_x(iw);   // (rq, ri) = this plane's first step: its plane became visible at the barrier
-        for (int st = 0; st < nk; ++st) step();
+            for (int iw = 0; iw < 8; ++iw) ld_x(iw);
+        }
+        step();
+        if (STAGE_AT == 1 && !TWOB) stage();
+        for (int st = 1; st < nk; ++st) step();
         if (!(kd == 3 || (od == 3 && kd == 2))) continue;   // the row is complete after its last plane
         // ---- epilogue: the row's 4 positions, ascending; the two cout tiles ----
         const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * 64 * 8 * 32 + 16 * (hh & 1));

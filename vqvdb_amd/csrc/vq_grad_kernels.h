@@ -12,61 +12,85 @@
 // W is the raw PyTorch tensor [OC][IC][KT].  transpose = 0: forward fragments of rows [row0, row0+COUT) x CIN=IC.
 // transpose = 1: fragments of the data-gradient conv (stride 1): COUT' = IC, CIN' = sub-range [row0,row0+CIN) of OC, taps flipped.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void refrag32_k(const float* __restrict__ W, float* __restrict__ dst, int COUT, int CIN, int KT, int IC, int row0,
-                                                  int transpose, float scale)
+// ONE launch for all of them: the optimizer step rebuilds ~60 fragment tables and copies ~30 small vectors; as ~90 launches /
+// device-to-device copies of 3-4 us each (one kernel per table kind, rounds 1-3) that was 0.15-0.2 ms of a 4.8 ms step.  A job = one
+// table (kind, source, destination, integer parameters, element count, first workgroup); a workgroup looks its job up (the list is
+// sorted by first workgroup) and writes 256 elements.  Kinds:
+//   1  32x32x2 fragments [tap][u][mt][lane][i] = W(co = 32mt + (lane&31), ci = 8u + 4(lane>>5) + i, tap) of rows [row0, row0+COUT) x CIN = IC
+//   2  16x16x4 fragments of a 16 -> 16 layer [tap][lane][i] = W(co = lane&15, ci = 4(lane>>4)+i, tap)
+//   3  16x16x4 fragments of conv_rows16_k [tap][cb][mt][lane][i] = W(co = 16mt + (lane&15), ci = 16cb + 4(lane>>4) + i, tap)
+//   4  the first conv's K = {kw0, kw1, kw2, pad} fragments;  5  a per-cout vector in 32x32 D-fragment order;
+//   6  the down conv's transposed fragments [tap][blk][lane][i] = W[16 blk + 4(lane>>4) + i][lane & 15][tap];  0 copy;  7 zeros
+struct RefragJob {
+    const float* src;
+    float* dst;
+    int kind;      // 0 copy, 1 refrag32, 2 refrag16, 3 refrag16g, 4 refrag_first, 5 dfrag32, 6 refrag_down_t, 7 zero
+    int a, b, c, d, e, f;   // integer parameters of the kind (below)
+    float scale;
+    int total;     // elements
+    int wg0;       // first workgroup of this job
+};
+__global__ __launch_bounds__(256) void refrag_multi_k(const RefragJob* __restrict__ jobs, int n_jobs)
 {
-    const int NU = CIN / 8, NMT = COUT / 32;
-    const int64_t total = (int64_t)KT * NU * NMT * 64 * 4;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = n_jobs - 1;   // last job whose first workgroup is <= this one
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].wg0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const RefragJob J = jobs[lo];
+    const int t = ((int)blockIdx.x - J.wg0) * 256 + (int)threadIdx.x;
+    if (t >= J.total) return;
+    const float* __restrict__ W = J.src;
+    float v = 0.0f;
+    switch (J.kind) {
+    case 0: v = W[t]; break;
+    case 1: {   // COUT = a, CIN = b, KT = c, IC = d, row0 = e, transpose = f
+        const int NU = J.b / 8, NMT = J.a / 32, KT = J.c;
         const int i = t & 3, lane = (t >> 2) & 63;
-        int64_t r = t >> 8;
+        int r = t >> 8;
         const int mt = r % NMT;
         r /= NMT;
-        const int u = r % NU, tap = (int)(r / NU);
+        const int u = r % NU, tap = r / NU;
         const int co = 32 * mt + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + i;
-        const float v = transpose ? W[((int64_t)(row0 + ci) * IC + co) * KT + (KT - 1 - tap)] : W[((int64_t)(row0 + co) * IC + ci) * KT + tap];
-        dst[t] = scale * v;
+        v = J.scale * (J.f ? W[((int64_t)(J.e + ci) * J.d + co) * KT + (KT - 1 - tap)] : W[((int64_t)(J.e + co) * J.d + ci) * KT + tap]);
+        break;
     }
-}
-// 16x16x4 fragments for 16 -> 16 layers: [tap][lane][i] = W(co = lane&15, ci = 4(lane>>4)+i, tap)
-__global__ __launch_bounds__(256) void refrag16_k(const float* __restrict__ W, float* __restrict__ dst, int KT, int transpose, float scale)
-{
-    const int total = KT * 64 * 4;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int i = t & 3, lane = (t >> 2) & 63, tap = t >> 8;
+    case 2: {   // KT = a, transpose = b
+        const int KT = J.a, i = t & 3, lane = (t >> 2) & 63, tap = t >> 8;
         const int co = lane & 15, ci = 4 * (lane >> 4) + i;
-        dst[t] = scale * (transpose ? W[(ci * 16 + co) * KT + (KT - 1 - tap)] : W[(co * 16 + ci) * KT + tap]);
+        v = J.scale * (J.b ? W[(ci * 16 + co) * KT + (KT - 1 - tap)] : W[(co * 16 + ci) * KT + tap]);
+        break;
     }
-}
-// 16x16x4 fragments of conv_rows16_k: [tap][cb][mt][lane][i] = Wsrc(co = 16mt + (lane&15), ci = 16cb + 4(lane>>4) + i, tap).
-// transpose = 0: Wsrc = W[co][ci][tap] (W is [COUT][CIN][KT]).  transpose = 1 (data-gradient conv, stride 1): W is [CIN][COUT][KT] and
-// Wsrc(co, ci, tap) = W[ci][co][KT-1-tap].
-__global__ __launch_bounds__(256) void refrag16g_k(const float* __restrict__ W, float* __restrict__ dst, int COUT, int CIN, int KT, int transpose, float scale)
-{
-    const int CBN = CIN / 16, MTN = COUT / 16;
-    const int total = KT * CBN * MTN * 256;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    case 3: {   // COUT = a, CIN = b, KT = c, transpose = d
+        const int COUT = J.a, CIN = J.b, KT = J.c, CBN = CIN / 16, MTN = COUT / 16;
         const int i = t & 3, lane = (t >> 2) & 63;
         int r = t >> 8;
         const int mt = r % MTN;
         r /= MTN;
         const int cb = r % CBN, tap = r / CBN;
         const int co = 16 * mt + (lane & 15), ci = 16 * cb + 4 * (lane >> 4) + i;
-        dst[t] = scale * (transpose ? W[((size_t)ci * COUT + co) * KT + (KT - 1 - tap)] : W[((size_t)co * CIN + ci) * KT + tap]);
+        v = J.scale * (J.d ? W[((size_t)ci * COUT + co) * KT + (KT - 1 - tap)] : W[((size_t)co * CIN + ci) * KT + tap]);
+        break;
     }
-}
-__global__ __launch_bounds__(64) void refrag_first_k(const float* __restrict__ W, float* __restrict__ dst)
-{
-    const int lane = threadIdx.x, kw = lane >> 4;
-    for (int t = 0; t < 9; ++t) dst[t * 64 + lane] = kw < 3 ? W[(lane & 15) * 27 + t * 3 + kw] : 0.0f;
-}
-// D-fragment order of a per-cout vector: [(mt*2+q)*16 + r] = v[row0 + 32mt + (r&3) + 8(r>>2) + 4q]
-__global__ __launch_bounds__(256) void dfrag32_k(const float* __restrict__ v, float* __restrict__ dst, int COUT, int row0)
-{
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= COUT) return;
-    const int mt = f / 32, q = (f / 16) % 2, r = f % 16;
-    dst[f] = v[row0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q];
+    case 4: {   // dst[(kd*3+kh) * 64 + lane] = kw < 3 ? W[(lane & 15) * 27 + (kd*3+kh) * 3 + kw] : 0, kw = lane >> 4
+        const int lane = t & 63, t9 = t >> 6, kw = lane >> 4;
+        v = kw < 3 ? W[(lane & 15) * 27 + t9 * 3 + kw] : 0.0f;
+        break;
+    }
+    case 5: {   // [(mt*2+q)*16 + r] = v[row0 + 32mt + (r&3) + 8(r>>2) + 4q], row0 = a
+        const int mt = t / 32, q = (t / 16) % 2, r = t % 16;
+        v = W[J.a + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * q];
+        break;
+    }
+    case 6: {
+        const int i = t & 3, lane = (t >> 2) & 63, tb = t >> 8, tap = tb >> 1, blk = tb & 1;
+        v = W[((size_t)(16 * blk + 4 * (lane >> 4) + i) * 16 + (lane & 15)) * 64 + tap];
+        break;
+    }
+    default: break;   // 7: zero
+    }
+    J.dst[t] = v;
 }
 
 // quantized latent as the decoder's input (F.embedding + permute, VQVAE_v2.py:127-131): q[tile][pos][32 quads][32][4] = E[idx[leaf][pos]]
@@ -1121,19 +1145,39 @@ __global__ __launch_bounds__(64 * C / 8) void gn_bwd_sums_k(const float* __restr
     }
 }
 // out[tile][i] = sum over the n_split position ranges of part[tile][range][i]   (i over G*32 values per tile)
-__global__ __launch_bounds__(256) void gn_bwd_combine_k(const float* __restrict__ p1, const float* __restrict__ p2, int n_split, int per_tile, int n_tiles,
-                                                        float* __restrict__ o1, float* __restrict__ o2)
+// ... and, in the same launch (the workgroups behind the combine's), the two per-channel reductions of the GroupNorm-affine gradients
+// (chan_reduce_k's arithmetic for dgamma and dbeta): three launches of 5-15 us on the data-gradient chain became one
+__global__ __launch_bounds__(256) void gn_bwd_finish_k(const float* __restrict__ p1, const float* __restrict__ p2, int n_split, int per_tile, int n_tiles,
+                                                       float* __restrict__ o1, float* __restrict__ o2, const float* __restrict__ part_g,
+                                                       const float* __restrict__ part_b, int C, float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_tiles * per_tile) return;
-    const int tile = t / per_tile, i = t % per_tile;
-    float a = 0.0f, b = 0.0f;
-    for (int sp = 0; sp < n_split; ++sp) {
-        a += p1[((size_t)tile * n_split + sp) * per_tile + i];
-        b += p2[((size_t)tile * n_split + sp) * per_tile + i];
+    const int nb = (n_tiles * per_tile + 255) / 256;
+    if ((int)blockIdx.x < nb) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        if (t >= n_tiles * per_tile) return;
+        const int tile = t / per_tile, i = t % per_tile;
+        float a = 0.0f, b = 0.0f;
+        for (int sp = 0; sp < n_split; ++sp) {
+            a += p1[((size_t)tile * n_split + sp) * per_tile + i];
+            b += p2[((size_t)tile * n_split + sp) * per_tile + i];
+        }
+        o1[t] = a;
+        o2[t] = b;
+        return;
     }
-    o1[t] = a;
-    o2[t] = b;
+    __shared__ float red[256];
+    const int cb = (int)blockIdx.x - nb, c = cb % C, t = threadIdx.x;
+    const float* __restrict__ part = cb < C ? part_g : part_b;
+    const int nt2 = n_tiles * n_split;
+    float s = 0.0f;
+    for (int tile = t >> 5; tile < nt2; tile += 8) s += part[((size_t)tile * C + c) * 32 + (t & 31)];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) (cb < C ? dgamma : dbeta)[c] = red[0];
 }
 template <int C, int NP, int CPG>
 __global__ __launch_bounds__(256) void gn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ da, const float* __restrict__ mean,
@@ -1276,17 +1320,6 @@ __global__ __launch_bounds__(256) void st_grad_k(const float* __restrict__ dq, c
 // taps per axis.  One wave per 16-leaf half tile walks the 512 voxels.
 // wfrag[((tap*2 + blk)*64 + lane)*4 + i] = W[16 blk + 4 (lane>>4) + i][lane & 15][tap]
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void refrag_down_t_k(const float* __restrict__ W, float* __restrict__ dst)
-{
-    const int lane = threadIdx.x;
-    for (int t = blockIdx.x; t < 64 * 2; t += gridDim.x) {
-        const int tap = t >> 1, blk = t & 1;
-        f32x4 v;
-        float* o = (float*)&v;
-        for (int i = 0; i < 4; ++i) o[i] = W[((size_t)(16 * blk + 4 * (lane >> 4) + i) * 16 + (lane & 15)) * 64 + tap];
-        ((f32x4*)dst)[(size_t)t * 64 + lane] = v;
-    }
-}
 __global__ __launch_bounds__(256) void deconv_down_k(const float* __restrict__ dy /*L4 32ch@4^3*/, const float* __restrict__ wfrag, float* __restrict__ dx /*L4 16ch@8^3*/,
                                                      int n_tiles)
 {

@@ -217,6 +217,8 @@ struct vqhip_codec {
     std::vector<float> h_params;                                   // raw tensors, state_dict order
     std::map<std::string, std::pair<int64_t, int64_t>> p_off;      // name -> (offset, count) in the flat parameter vector
     float *ft_P = nullptr, *ft_M = nullptr, *ft_V = nullptr;       // parameters, AdamW moments (device, flat)
+    void* ft_refrag_jobs = nullptr;                                 // device job table of refrag_multi_k (vq_train_full.inc: refrag_all)
+    int ft_refrag_n = 0, ft_refrag_wgs = 0;
     char* ft_ws = nullptr;                                         // training workspace (saved activations, gradients)
     int64_t ft_tiles = 0;
     char* ft_part = nullptr;                                       // partial-gradient scratch
@@ -1743,6 +1745,7 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->tr_z) hipFree(c->tr_z);
     if (c->tr_idx) hipFree(c->tr_idx);
     if (c->tr_part) hipFree(c->tr_part);
+    if (c->ft_refrag_jobs) hipFree(c->ft_refrag_jobs);
     if (c->ft_P) hipFree(c->ft_P);
     if (c->ft_M) hipFree(c->ft_M);
     if (c->ft_V) hipFree(c->ft_V);
