@@ -72,9 +72,9 @@ int main()
         hipDeviceSynchronize();
         ConvArgs D = A;
         D.wfrag = wd, D.in = din;
-#define RD(ABL, TWOB) run("conv_down_lds_k ABL " #ABL " TWOB " #TWOB, conv_down_lds_k<ABL, TWOB>, D, cus, 512, LDS_CONVDOWN)
-#define RDS(S) run("conv_down_lds_k one barrier, staging at " #S, conv_down_lds_k<0, false, S>, D, cus, 512, LDS_CONVDOWN)
-        RDS(0); RDS(1); RD(0, true); RDS(0); RDS(1); RD(0, true); RD(1, false); RD(2, false); RD(4, false); RD(8, false); RD(16, false);
+#define RD(ABL, TWOB) run("conv_down_lds_k 16 waves ABL " #ABL " TWOB " #TWOB, conv_down_lds_k<ABL, TWOB>, D, cus, 1024, LDS_CONVDOWN)
+#define RD8(ABL) run("conv_down_lds_k 8 waves ABL " #ABL, conv_down_lds_k<ABL, false, 1, 8>, D, cus, 512, LDS_CONVDOWN)
+        RD8(0); RD(0, false); RD8(0); RD(0, false); RD(0, true); RD(1, false); RD(2, false); RD(4, false); RD(8, false); RD(16, false);
     }
     return 0;
 }

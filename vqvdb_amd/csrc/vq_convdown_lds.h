@@ -26,40 +26,47 @@
 constexpr size_t LDS_CONVDOWN = (size_t)2 * 4096 * 16 + (size_t)8 * 2 * 2 * 2 * 64 * 8;   // 131 072 + 32 768 B = all 160 KB
 
 // ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads
-template <int ABL = 0, bool TWOB = false, int STAGE_AT = 1>
-__global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
+// NW: 8 waves (a wave holds both 16-cout tiles of its row: 8 accumulators) or 16 (one tile each: four waves per SIMD hide one another's
+// staging, epilogue and barrier skew; the A-fragment traffic is the same, the B operands are read twice).
+template <int ABL = 0, bool TWOB = false, int STAGE_AT = 1, int NW = 16>
+__global__ __launch_bounds__(NW * 64, 1) void conv_down_lds_k(ConvArgs A)
 {
     static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* slots = (f32x4*)smem_raw;                                    // [2][64 pos][4 quads][16 leaves]
-    double* xch = (double*)(smem_raw + (size_t)2 * 4096 * 16);          // [wave 8][row 2][mt 2][2][64 lanes]
+    double* xch = (double*)(smem_raw + (size_t)2 * 4096 * 16);          // [wave NW][row 2][tile of the wave MTW][2][64 lanes]
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    constexpr int MTW = NW == 8 ? 2 : 1, NPW = 64 / NW;                  // cout tiles per wave; positions a wave stages per plane
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, j16 = lane & 15;
     // waves w and w+4 share a SIMD: (g, oh) = (0, w) and (1, perm(w-4)), perm = 1,0,3,2 -> one border and one inner row per SIMD
-    const int g = wave >> 2, oh = g ? ((wave & 3) ^ 1) : wave;
+    const int w8 = wave & 7, mt0 = NW == 8 ? 0 : wave >> 3;              // (16 waves: waves w and w+8 = the two cout tiles of one row)
+    const int g = w8 >> 2, oh = g ? ((w8 & 3) ^ 1) : w8;
     const int k0 = oh == 0 ? 1 : 0, nk = (oh == 0 || oh == 3) ? 3 : 4;   // valid kh (ih = 2 oh - 1 + kh in 0..7): k0 .. k0 + nk - 1
     const int n_half = 2 * A.n_tiles;
     if ((int)blockIdx.x >= n_half) return;
     const int n_my = (n_half - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int NPL = n_my * 8;                                             // input planes this workgroup walks
     const unsigned lane_b = (unsigned)(q4 * 32 + j16) * 16u;
-    const f32x4 bias4[2] = {((const f32x4*)A.bias_frag)[q4], ((const f32x4*)A.bias_frag)[4 + q4]};
+    f32x4 bias4[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) bias4[m] = ((const f32x4*)A.bias_frag)[4 * (mt0 + m) + q4];
     const vq_buf wb = buf_of(A.wfrag);
     const unsigned lane_w = (unsigned)lane * 16u;
 
-    // ---- plane staging: wave w brings in input row ih = w (8 positions) of every plane: a plain copy, the input is raw ----
-    f32x4 pf[8];
+    // ---- plane staging: wave w brings in NPW consecutive positions of every plane: a plain copy, the input is raw ----
+    f32x4 pf[NPW];
     auto issue_prefetch = [&](int Q) __attribute__((always_inline)) {
         const int hh = (int)blockIdx.x + (Q >> 3) * (int)gridDim.x, id = Q & 7;
         const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)(hh >> 1) * 512 * 4 * 32 + 16 * (hh & 1));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pf[k] = buf_ld16(inb, lane_b, (unsigned)(id * 64 + wave * 8 + k) * 2048u);
+        for (int k = 0; k < NPW; ++k) pf[k] = buf_ld16(inb, lane_b, (unsigned)(id * 64 + wave * NPW + k) * 2048u);
     };
     auto write_plane = [&](int Q) __attribute__((always_inline)) {
-        f32x4* dst = slots + (Q & 1) * 4096 + ((wave * 8) * 4 + q4) * 16 + j16;
+        f32x4* dst = slots + (Q & 1) * 4096 + ((wave * NPW) * 4 + q4) * 16 + j16;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k * 4 * 16] = pf[k];
+        for (int k = 0; k < NPW; ++k) dst[k * 4 * 16] = pf[k];
     };
 
     // which (od, kd) of this wave input plane id feeds: od of parity g among od_a = (id+1)/2 (kd = (id+1)%2) and od_a - 1 (kd + 2)
@@ -67,13 +74,13 @@ __global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
     auto kd_of = [&](int id) { const int oa = (id + 1) >> 1; return ((id + 1) & 1) + ((oa & 1) == g ? 0 : 2); };
     auto works = [&](int id) { const int o = od_of(id); return o >= 0 && o <= 3; };
 
-    f32x4 acc[4][2];
+    f32x4 acc[4][MTW];
     // Operands of one (kd, kh) step: a[kw][mt] = A fragments of taps (kd*4 + kh)*4 + kw (global memory: L1 / L2 hits), x[iw] = the 8
     // positions of input row ih = 2 oh - 1 + kh of the plane (LDS).  One register set; every operand is re-requested for the next step
     // of the stream (this plane's next kh, else the first kh of this wave's next working plane) right after its last MFMA.  Requests
     // are unconditional.  The LDS re-requests at a plane's last step read a slot that is still being written: they are repeated
     // after the barrier (x_all), the early copy is never used.
-    f32x4 a[4][2], x[8];
+    f32x4 a[4][MTW], x[8];
     int rq = 0, ri = 0;                 // the step being requested: input plane, kh - k0
     auto advance = [&]() __attribute__((always_inline)) {
         if (++ri == nk) {
@@ -85,86 +92,67 @@ __global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
     auto ld_a = [&](int kw) __attribute__((always_inline)) {
         const unsigned t = (unsigned)((kd_of(rq & 7) * 4 + k0 + ri) * 4 + kw);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a[kw][mt] = (ABL & 16) ? bias4[mt] : buf_ld16(wb, lane_w, (t * 2 + mt) * 1024u);
+        for (int m = 0; m < MTW; ++m) a[kw][m] = (ABL & 16) ? bias4[m] : buf_ld16(wb, lane_w, (t * 2 + mt0 + m) * 1024u);
     };
     auto ld_x = [&](int iw) __attribute__((always_inline)) {
         x[iw] = (ABL & 8) ? bias4[0] : slots[(rq & 1) * 4096 + (((2 * oh - 1 + k0 + ri) * 8 + iw) * 4 + q4) * 16 + j16];
     };
-    // one (ow, kw) pair: 8 MFMAs, k outer, the two cout tiles alternating (independent accumulators)
-    auto pair = [&](int ow, int kw) __attribute__((always_inline)) {
-        const int iw = 2 * ow - 1 + kw;
+    // The step's fourteen (ow, kw) pairs in kw-major order — kw 0: ow 1,2,3 | kw 1: ow 0..3 | kw 2: ow 0..3 | kw 3: ow 0,1,2: every accumulator
+    // sees its kw ascending — run as seven groups of two pairs whose MFMAs alternate (different outputs: independent accumulators), each
+    // pair's MFMAs in k order.  Every operand is re-requested for the next step right after its last use, at least two groups (~1 k
+    // cycles) before its first use there:
+    //   G1 (1,0)(2,0) | G2 (3,0)(0,1): a0 x0 | G3 (1,1)(2,1) | G4 (3,1)(0,2): a1 x1 | G5 (1,2)(2,2): x3 x5 | G6 (3,2)(0,3): a2 x7 x2 | G7 (1,3)(2,3): a3 x4 x6
+    auto group = [&](int owA, int kwA, int owB, int kwB) __attribute__((always_inline)) {
+        const int iwA = 2 * owA - 1 + kwA, iwB = 2 * owB - 1 + kwB;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[ow][mt] = mfma16(a[kw][mt][k], x[iw][k], acc[ow][mt]);
+            for (int m = 0; m < MTW; ++m) {
+                acc[owA][m] = mfma16(a[kwA][m][k], x[iwA][k], acc[owA][m]);
+                acc[owB][m] = mfma16(a[kwB][m][k], x[iwB][k], acc[owB][m]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
     };
-    // kw-major: kw 0: ow 1,2,3 | kw 1: ow 0..3 | kw 2: ow 0..3 | kw 3: ow 0,1,2 — every accumulator sees its kw ascending.  Last uses:
-    // a[0] after (3,0), a[1] after (3,1), a[2] after (3,2), a[3] after (2,3); x1 (0,2), x3 (1,2), x5 (2,2), x7 (3,2), x0 (0,1), x2 (0,3),
-    // x4 (1,3), x6 (2,3): every re-request is at least six pairs (1.5 k cycles) ahead of its first use in the next step.
     auto step = [&]() __attribute__((always_inline)) {
         advance();   // (rq, ri): the NEXT step — what the re-requests below fetch
-        pair(1, 0), pair(2, 0), pair(3, 0);
+        group(1, 0, 2, 0);
+        group(3, 0, 0, 1);
+        ld_a(0), ld_x(0);
         __builtin_amdgcn_sched_barrier(0);
-        ld_a(0);
+        group(1, 1, 2, 1);
+        group(3, 1, 0, 2);
+        ld_a(1), ld_x(1);
         __builtin_amdgcn_sched_barrier(0);
-        pair(0, 1);
+        group(1, 2, 2, 2);
+        ld_x(3), ld_x(5);
         __builtin_amdgcn_sched_barrier(0);
-        ld_x(0);
+        group(3, 2, 0, 3);
+        ld_a(2), ld_x(7), ld_x(2);
         __builtin_amdgcn_sched_barrier(0);
-        pair(1, 1), pair(2, 1), pair(3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_a(1);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_x(1);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(1, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_x(3);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(2, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_x(5);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(3, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_a(2);
-        ld_x(7);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(0, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_x(2);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_x(4);
-        __builtin_amdgcn_sched_barrier(0);
-        pair(2, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_a(3);
-        ld_x(6);
+        group(1, 3, 2, 3);
+        ld_a(3), ld_x(4), ld_x(6);
         __builtin_amdgcn_sched_barrier(0);
     };
 
     // block sums of this wave's two rows (od = g, g + 2) of the current half tile, per cout tile
-    double bs[2][2], bq[2][2];
-    auto finish_stats = [&](int hh) __attribute__((always_inline)) {   // wave 0: the sixteen blocks of half tile hh in block order
-        if (wave != 0) return;
+    double bs[2][MTW], bq[2][MTW];
+    auto finish_stats = [&](int hh) __attribute__((always_inline)) {   // the row (g, oh) = (0, 0) wave(s): the sixteen blocks of half tile hh in block order
+        if (w8 != 0) return;
         const int tile = hh >> 1, jj = j16 + 16 * (hh & 1);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = mt0 + m;
             double S = 0.0, Q = 0.0;
 #pragma unroll
             for (int blk = 0; blk < 16; ++blk) {
                 const int o = blk & 3, d = blk >> 2;                  // block = output row (od = d, oh = o)
-                const int wv = (d & 1) ? 4 + (o ^ 1) : o;              // its wave: g = d & 1, oh = o
-                S += xch[(((wv * 2 + (d >> 1)) * 2 + mt) * 2 + 0) * 64 + lane];
-                Q += xch[(((wv * 2 + (d >> 1)) * 2 + mt) * 2 + 1) * 64 + lane];
+                const int wv = ((d & 1) ? 4 + (o ^ 1) : o) + (NW == 8 ? 0 : 8 * mt);   // its wave: g = d & 1, oh = o (, cout tile)
+                S += xch[(((wv * 2 + (d >> 1)) * MTW + m) * 2 + 0) * 64 + lane];
+                Q += xch[(((wv * 2 + (d >> 1)) * MTW + m) * 2 + 1) * 64 + lane];
             }
-            float m, r;
-            gn_finish(S, Q, 1.0 / 256.0, m, r);   // GroupNorm(8,32): 4 channels x 64 positions
-            A.out_mean[((size_t)tile * 8 + 4 * mt + q4) * 32 + jj] = m;
+            float mm, r;
+            gn_finish(S, Q, 1.0 / 256.0, mm, r);   // GroupNorm(8,32): 4 channels x 64 positions
+            A.out_mean[((size_t)tile * 8 + 4 * mt + q4) * 32 + jj] = mm;
             A.out_rstd[((size_t)tile * 8 + 4 * mt + q4) * 32 + jj] = r;
         }
     };
@@ -199,7 +187,9 @@ __global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
         const int od = od_of(id), kd = kd_of(id);
         if (kd == 0 || (od == 0 && kd == 1)) {   // first plane of this output row
 #pragma unroll
-            for (int ow = 0; ow < 4; ++ow) acc[ow][0] = acc[ow][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int ow = 0; ow < 4; ++ow)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) acc[ow][m] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
         // (rq, ri) = this plane's first step.  One barrier per plane: its B operands can only be requested now (the early copy read a slot
         // that was still being written).  Two: only behind a plane this wave sat out (the early copy was requested two planes ahead).
@@ -213,38 +203,39 @@ __global__ __launch_bounds__(512, 1) void conv_down_lds_k(ConvArgs A)
         if (!(kd == 3 || (od == 3 && kd == 2))) continue;   // the row is complete after its last plane
         // ---- epilogue: the row's 4 positions, ascending; the two cout tiles ----
         const vq_buf outb = buf_of((const f32x4*)A.out + (size_t)tile * 64 * 8 * 32 + 16 * (hh & 1));
-        GnAcc st[2];
-        st[0].init(), st[1].init();
+        GnAcc st[MTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) st[m].init();
         if (!(ABL & 2)) {
 #pragma unroll
             for (int ow = 0; ow < 4; ++ow)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const f32x4 v = acc[ow][mt] + bias4[mt];
-                    buf_st16_nt(v, outb, lane_b + mt * 2048, (unsigned)((od * 4 + oh) * 4 + ow) * 4096u);
-                    st[mt].add(v.x);
-                    st[mt].add(v.y);
-                    st[mt].add(v.z);
-                    st[mt].add(v.w);
+                for (int m = 0; m < MTW; ++m) {
+                    const f32x4 v = acc[ow][m] + bias4[m];
+                    buf_st16_nt(v, outb, lane_b + (mt0 + m) * 2048, (unsigned)((od * 4 + oh) * 4 + ow) * 4096u);
+                    st[m].add(v.x);
+                    st[m].add(v.y);
+                    st[m].add(v.z);
+                    st[m].add(v.w);
                 }
         } else {
             float t = 0.0f;
 #pragma unroll
-            for (int ow = 0; ow < 4; ++ow) t += acc[ow][0].x + acc[ow][1].w;
+            for (int ow = 0; ow < 4; ++ow) t += acc[ow][0].x + acc[ow][MTW - 1].w;
             if (t == 12345.678f) ((f32x4*)A.out)[tid] = acc[0][0];
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            if (od >> 1) bs[1][mt] = st[mt].bs, bq[1][mt] = st[mt].bq;
-            else bs[0][mt] = st[mt].bs, bq[0][mt] = st[mt].bq;
+        for (int m = 0; m < MTW; ++m) {
+            if (od >> 1) bs[1][m] = st[m].bs, bq[1][m] = st[m].bq;
+            else bs[0][m] = st[m].bs, bq[0][m] = st[m].bq;
         }
-        if (od >> 1) {   // this wave's second row: both of its blocks go to LDS (read by wave 0 after the next barrier)
+        if (od >> 1) {   // this wave's second row: both of its blocks go to LDS (read by the (0, 0) waves after the next barrier)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    xch[(((wave * 2 + r) * 2 + mt) * 2 + 0) * 64 + lane] = bs[r][mt];
-                    xch[(((wave * 2 + r) * 2 + mt) * 2 + 1) * 64 + lane] = bq[r][mt];
+                for (int m = 0; m < MTW; ++m) {
+                    xch[(((wave * 2 + r) * MTW + m) * 2 + 0) * 64 + lane] = bs[r][m];
+                    xch[(((wave * 2 + r) * MTW + m) * 2 + 1) * 64 + lane] = bq[r][m];
                 }
         }
     }

@@ -1198,7 +1198,7 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         A.in = a["e_a6"], A.out = a["e_x7"], A.wfrag = w["ed.w16"], A.bias_frag = w["ed.braw"];
         A.out_mean = S.x7m, A.out_rstd = S.x7r, A.n_tiles = nt;
         A.n_steps = c->nsteps["steps.rows_k4s2_8"], A.n_taps = 64;
-        if (c->convdown_lds) L.run("enc_down", [&] { hipLaunchKernelGGL(conv_down_lds_k<0>, dim3(std::min(2 * nt, c->n_cus)), dim3(512), LDS_CONVDOWN, s, A); });
+        if (c->convdown_lds) L.run("enc_down", [&] { hipLaunchKernelGGL(conv_down_lds_k<0>, dim3(std::min(2 * nt, c->n_cus)), dim3(1024), LDS_CONVDOWN, s, A); });
         else L.run("enc_down", [&] { hipLaunchKernelGGL(k_enc_down_r, dim3((2 * nt + 7) / 8), dim3(512), LDS_ENC_DOWN_R, s, A, (const int4*)w["steps.rows_k4s2_8"]); });
     }
     {
