@@ -487,12 +487,15 @@ def test_denormal_and_tiny_inputs_match_oracle(codec, oracle):
 def test_large_path_kernel_variants_agree(pack, oracle, monkeypatch):
     """The large-batch kernels have selectable variants (VQHIP_CONV8 = w8 | rows: 8-wave LDS-plane kernel / row-group kernel for the
     16-channel convs instead of the 16-wave one; VQHIP_STEM=split: gather and GroupNorm as two kernels; VQHIP_STEM=gather: the fused decoder front gathering the (tap, code)
-    table through the L1 (stem_fused_k) instead of streaming it through an LDS ring tap by tap (stem_taps_k, the default)).  All of them implement the
-    same arithmetic contract: identical indices and voxels, and the oracle's on a sample."""
-    leaves = np.concatenate([synth.make_leaves(2200, seed=31), synth.edge_leaves()])
+    table through the L1 (stem_fused_k) instead of streaming it through an LDS ring tap by tap (stem_taps_k, the default); VQHIP_CONV4=rows /
+    VQHIP_DOWN=rows: the encoder's 4^3 convs on the row kernel — weights in LDS, input rows re-loaded — instead of the LDS plane rings
+    conv4_lds_k / conv_down_lds_k).  All of them implement the same arithmetic contract: identical indices, voxels and (debug mode)
+    encoder intermediates, and the oracle's on a sample."""
+    leaves = np.concatenate([synth.make_leaves(2200, seed=31), synth.sparse_leaves(300, seed=32), synth.edge_leaves()])
     ref_idx = ref_rec = None
-    for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}, {"VQHIP_STEM": "gather"}):
-        for k in ("VQHIP_CONV8", "VQHIP_STEM"):
+    for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}, {"VQHIP_STEM": "gather"}, {"VQHIP_CONV4": "rows"},
+                {"VQHIP_DOWN": "rows"}, {"VQHIP_CONV4": "rows", "VQHIP_DOWN": "rows"}):
+        for k in ("VQHIP_CONV8", "VQHIP_STEM", "VQHIP_CONV4", "VQHIP_DOWN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -1458,8 +1458,16 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
         const int pn = p < 63 ? p + 1 : 63;
 #pragma unroll
         for (int u = 0; u < 4; ++u) bn[u] = in4[((size_t)pn * 8 + 2 * u) * 32];
+        // Scan (round 4).  Per code tile: the maximum of the lane's 16 candidates by a v_max3 tree (8 ops), "did the tile beat the running
+        // best" (strictly: an earlier tile keeps a tie), the new best, the tile's number, and the tile's 16 scores kept where it won
+        // (16 selects) — 27 vector ops per tile where compare + two selects per candidate took 48; the candidate's number inside the
+        // winning tile is found ONCE per position (first score equal to the best: 32 ops).  Same result as the sequential scan: first
+        // maximum = torch.argmin's first minimum.
         float best = -__builtin_inff();
-        int bk = 0;
+        int bt = 0;
+        f32x16 sv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = 0.0f;
         const f32x4* el = ldsE + lane;
 #pragma unroll 2
         for (int ct = 0; ct < 8; ++ct) {
@@ -1468,8 +1476,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             f32x4 ck[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) ck[g] = ldsC[(ct * 2 + q) * 4 + g];
-            // the chain of candidate k starts at h_k = -c_k / 2 (the MFMA's C operand) and ends as  h_k + x'.Ep_k = -score_k / 2:
-            // nearest code = FIRST MAXIMUM, no per-candidate score op (round 3; c_k - 2 dot after a chain from zero before)
+            // the chain of candidate k starts at h_k = -c_k / 2 (the MFMA's C operand) and ends as  h_k + x'.Ep_k = -score_k / 2
             f32x16 d;
 #pragma unroll
             for (int g = 0; g < 4; ++g) d[4 * g + 0] = ck[g].x, d[4 * g + 1] = ck[g].y, d[4 * g + 2] = ck[g].z, d[4 * g + 3] = ck[g].w;
@@ -1489,24 +1496,22 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             d = mfma32(a3.y, b[3].y, d);
             d = mfma32(a3.z, b[3].z, d);
             d = mfma32(a3.w, b[3].w, d);
-            // Three vector ops per candidate (compare, two selects).  The select of the index takes the candidate's number INSIDE the tile
-            // (i + 8g <= 27: an inline constant; 32 ct + i + 8g is a literal the compiler first moves into a register, one more op per
-            // candidate); 63 = "no candidate of this tile beat the running best", the tile offset joins once per tile; the lane's own
-            // code offset 4q once per position.
-            int loc = 63;
+            const float t0 = __builtin_fmaxf(__builtin_fmaxf(d[0], d[1]), d[2]), t1 = __builtin_fmaxf(__builtin_fmaxf(d[3], d[4]), d[5]);
+            const float t2 = __builtin_fmaxf(__builtin_fmaxf(d[6], d[7]), d[8]), t3 = __builtin_fmaxf(__builtin_fmaxf(d[9], d[10]), d[11]);
+            const float t4 = __builtin_fmaxf(__builtin_fmaxf(d[12], d[13]), d[14]);
+            const float u0 = __builtin_fmaxf(__builtin_fmaxf(t0, t1), t2), u1 = __builtin_fmaxf(__builtin_fmaxf(t3, t4), d[15]);
+            const float m = __builtin_fmaxf(u0, u1);
+            const bool won = m > best;
+            best = __builtin_fmaxf(best, m);
+            bt = won ? ct : bt;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float score = d[4 * g + i];
-                    if (score > best) {
-                        best = score;
-                        loc = i + 8 * g;
-                    }
-                }
-            }
-            if (loc != 63) bk = 32 * ct + loc;
+            for (int r = 0; r < 16; ++r) sv[r] = won ? d[r] : sv[r];
         }
+        // register r of the winning tile holds code 32 bt + (r & 3) + 8 (r >> 2) (+ 4q): ascending in r, so the first r with sv[r] == best
+        int loc = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; --r) loc = sv[r] == best ? (r & 3) + 8 * (r >> 2) : loc;
+        int bk = 32 * bt + loc;
         bk += 4 * q;
         const float ob = __shfl_xor(best, 32, 64);
         const int ok = __shfl_xor(bk, 32, 64);
