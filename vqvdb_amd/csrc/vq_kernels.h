@@ -140,9 +140,11 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
 //   MODE 0: statistics of y1 = conv(x)+bias for GroupNorm(4,16) (no activation store unless A.out != 0)
 //   MODE 1: recompute y1, a1 = relu(gn(y1)) -> store, statistics of a1 for GroupNorm(8,16).
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+// ABL (tools/ablate/conv_first_ablate.hip only): 1 no input loads inside the loop, 2 no MFMAs, 4 no statistics, 8 no stores
+template <int MODE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* __restrict__ steps)
 {
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = blockIdx.x * 4 + wave;
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                 const int r = max(0, min((en.x >> 3) + (kh - 1), 63));
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
+                    if (ABL & 1) continue;
                     xn[kh][sb][0] = ldrow(r, sb, 0);
                     xn[kh][sb][1] = ldrow(r, sb, 1);
                 }
@@ -230,6 +233,10 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     const float wv = kh == 0 ? w0 : (kh == 1 ? w1 : w2);
 #pragma unroll
                     for (int ow = 0; ow < 8; ++ow) {
+                        if (ABL & 2) {
+                            acc[ow][0].x += wv + xc[kh][0][ow >> 2][ow & 3], acc[ow][1].x += wv + xc[kh][1][ow >> 2][ow & 3];
+                            continue;
+                        }
                         acc[ow][0] = mfma16(wv, xc[kh][0][ow >> 2][ow & 3], acc[ow][0]);
                         acc[ow][1] = mfma16(wv, xc[kh][1][ow >> 2][ow & 3], acc[ow][1]);
                     }
@@ -253,6 +260,10 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     st[sb][0].add(v.w);
                 } else if (MODE == 0) {
                     if (has_out) buf_st16(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);   // debug only
+                    if (ABL & 4) {
+                        st[sb][0].bs += (double)(v.x + v.y + v.z + v.w);
+                        continue;
+                    }
                     st[sb][0].add(v.x);
                     st[sb][0].add(v.y);
                     st[sb][0].add(v.z);
@@ -264,7 +275,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     v.w = fmaxf(__builtin_fmaf(v.w, ia[sb][3], ib[sb][3]), 0.0f);
                     // streaming (nontemporal) store: the 2.1 GB of a1 are read by the next kernel from HBM anyway, and a plain store's
                     // write-allocate traffic through L2 made this pass store-bound (0.65 -> 0.45 ms)
-                    buf_st16_nt(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);
+                    if (!(ABL & 8)) buf_st16_nt(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);
+                    if (ABL & 4) {
+                        st[sb][0].bs += (double)(v.x + v.y), st[sb][1].bs += (double)(v.z + v.w);
+                        continue;
+                    }
                     st[sb][0].add(v.x);
                     st[sb][0].add(v.y);
                     st[sb][1].add(v.z);
@@ -1409,11 +1424,18 @@ struct VqArgs {
     int n_tiles;
 };
 
-template <int NW>
+// SCAN: how the winning tile's scores are kept.  0: sixteen selects per tile (v_cndmask).  1: under the lanes-that-won EXEC mask
+// (a divergent branch: the copies are plain moves, two registers each where the compiler finds v_pk_mov_b32 / v_mov_b64 — it
+// if-converts the branch back into the selects).  2: in LDS — the lanes that won store the tile's 16 scores into their own 64-byte
+// slot (4 ds_write_b128 under the EXEC mask: no vector-ALU slot at all on the pipe the MFMAs share), read back once per position.
+// ABL (tools/ablate only): 1 no scan at all, 2 no score keeping, 4 no MFMAs
+template <int NW, int SCAN = 0, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
 {
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
     __shared__ f32x4 ldsE[4 * 8 * 64];  // 32 KB
     __shared__ f32x4 ldsC[8 * 2 * 4];   // 1 KB
+    __shared__ f32x4 ldsS[SCAN == 2 ? NW * 4 * 64 : 1];   // SCAN 2: [wave][score quad g][lane], 4 KB per wave
     for (int i = threadIdx.x; i < 4 * 8 * 64; i += NW * 64) ldsE[i] = ((const f32x4*)A.epfrag)[i];
     for (int i = threadIdx.x; i < 8 * 2 * 4; i += NW * 64) ldsC[i] = ((const f32x4*)A.ck_frag)[i];
     __syncthreads();
@@ -1480,6 +1502,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             f32x16 d;
 #pragma unroll
             for (int g = 0; g < 4; ++g) d[4 * g + 0] = ck[g].x, d[4 * g + 1] = ck[g].y, d[4 * g + 2] = ck[g].z, d[4 * g + 3] = ck[g].w;
+            if (!(ABL & 4)) {
             d = mfma32(a0.x, b[0].x, d);
             d = mfma32(a0.y, b[0].y, d);
             d = mfma32(a0.z, b[0].z, d);
@@ -1496,6 +1519,14 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             d = mfma32(a3.y, b[3].y, d);
             d = mfma32(a3.z, b[3].z, d);
             d = mfma32(a3.w, b[3].w, d);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] += a0.x * b[r & 3].x + a1.y * b[r & 3].y + a2.z + a3.w;
+            }
+            if (ABL & 1) {
+                best += d[0] + d[5] + d[10] + d[15];
+                continue;
+            }
             const float t0 = __builtin_fmaxf(__builtin_fmaxf(d[0], d[1]), d[2]), t1 = __builtin_fmaxf(__builtin_fmaxf(d[3], d[4]), d[5]);
             const float t2 = __builtin_fmaxf(__builtin_fmaxf(d[6], d[7]), d[8]), t3 = __builtin_fmaxf(__builtin_fmaxf(d[9], d[10]), d[11]);
             const float t4 = __builtin_fmaxf(__builtin_fmaxf(d[12], d[13]), d[14]);
@@ -1504,13 +1535,34 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
             const bool won = m > best;
             best = __builtin_fmaxf(best, m);
             bt = won ? ct : bt;
+            if (ABL & 2) continue;
+            if (SCAN == 2) {
+                if (won) {   // (divergent: stores under the EXEC mask of the lanes whose best moved)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sv[r] = won ? d[r] : sv[r];
+                    for (int g = 0; g < 4; ++g) ldsS[(wave * 4 + g) * 64 + lane] = (f32x4){d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                }
+            } else if (SCAN == 1) {
+                if (won) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sv[r] = d[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = won ? d[r] : sv[r];
+            }
         }
         // register r of the winning tile holds code 32 bt + (r & 3) + 8 (r >> 2) (+ 4q): ascending in r, so the first r with sv[r] == best
+        if (SCAN == 2) {   // (the wave's own stores, program order: every lane won at least tile 0, its slot is this position's)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 t = ldsS[(wave * 4 + g) * 64 + lane];
+                sv[4 * g] = t.x, sv[4 * g + 1] = t.y, sv[4 * g + 2] = t.z, sv[4 * g + 3] = t.w;
+            }
+        }
         int loc = 0;
 #pragma unroll
         for (int r = 15; r >= 0; --r) loc = sv[r] == best ? (r & 3) + 8 * (r >> 2) : loc;
+        if (SCAN == 2) loc = best > -__builtin_inff() ? loc : 0;   // a lane that never won (every score NaN or -inf) holds an older position's scores: code 0, as above
         int bk = 32 * bt + loc;
         bk += 4 * q;
         const float ob = __shfl_xor(best, 32, 64);
