@@ -23,14 +23,14 @@ def kernel_build_id():
     return h.hexdigest()[:12]
 
 LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the library's profiler)
-    (r"conv_first_k<0>", "enc_conv_first_stats"), (r"conv_first_k<1>", "enc_conv_first_gn"),
+    (r"conv_first_k<0[,>]", "enc_conv_first_stats"), (r"conv_first_k<1[,>]", "enc_conv_first_gn"),
     (r"conv8_c16_k<4, false, true, false>", "enc_res16_conv1"), (r"conv8_c16_k<4, true, false, false>", "enc_res16_conv2"),
     (r"conv8_lds_k<false, true", "enc_res16_conv1"), (r"conv8_lds_k<true, false", "enc_res16_conv2"),   # persistent grid = CUs: the large-batch launches
     (r"conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true[,>]", "enc_down"),
     (r"conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, false, 8, false, true[,>]", "enc_res32_conv1"),
     (r"conv_rows16_k<32, 32, 4, 4, 3, 1, 1, 1, true, 0, true, true[,>]", "enc_res32_conv2"),
     (r"conv_down_lds_k", "enc_down"), (r"conv4_lds_k<false, true, false", "enc_res32_conv1"), (r"conv4_lds_k<true, false, true", "enc_res32_conv2"),   # round 4: LDS plane rings
-    (r"vq_folded_k<8>", "enc_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
+    (r"vq_folded_k<8[,>]", "enc_vq"), (r"pack_leaves_k", "pack_leaves"), (r"stem_lut_k", "dec_stem"),
     (r"gn_relu_stats_k<64", "dec_gn_relu_stats"), (r"stem_fused_k", "dec_stem_gn"), (r"stem_taps_k", "dec_stem_gn"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false[,>]", "dec_res64_conv1"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false[,>]", "dec_res64_conv2"),
@@ -39,19 +39,18 @@ LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the lib
 
 
 def read(path, counter):
-    """Per launch name: the average counter value over the launches with the LARGEST grid of that kernel (the 65536-leaf launches of the
-    throughput legs; the same kernels also run at small batches and with gridDim.y > 1)."""
+    """Per launch name: the LARGEST counter value over the launches of the kernels that map to it = the 65536-leaf launches of the
+    throughput legs (the same kernels also run at small batches and with gridDim.y > 1; a persistent kernel has the same grid for its
+    65536-leaf launches and for mid-size passes; two kernels may share a launch name: stem_taps_k for full chunks, stem_fused_k below)."""
     db = sqlite3.connect(path)
-    out, best = {}, {}
-    # max, not avg: a persistent kernel (grid = CUs) has the same grid for its 65536-leaf launches and for mid-size passes
-    for name, grid, gy, avg in db.execute("select kernel_name, grid_size_x, grid_size_y, max(value) from counters_collection where counter_name=? "
+    out = {}
+    for name, grid, gy, top in db.execute("select kernel_name, grid_size_x, grid_size_y, max(value) from counters_collection where counter_name=? "
                                           "group by kernel_name, grid_size_x, grid_size_y", (counter,)):
-        if gy != 1 and not (gy == 2 and "vq_folded_k<8>" in name):   # position-split launches (small batches); the full-chunk VQ search runs two position ranges per tile
+        if gy != 1 and not (gy == 2 and re.search(r"vq_folded_k<8[,>]", name)):   # position-split launches (small batches); the full-chunk VQ search runs two position ranges per tile
             continue
         for rx, launch in LAUNCH:
-            if re.search(rx, name) and not name.startswith("build_") and grid > best.get(launch, -1):
-                best[launch] = grid
-                out[launch] = avg * 1024.0
+            if re.search(rx, name) and not name.startswith("build_"):
+                out[launch] = max(out.get(launch, 0.0), top * 1024.0)
     return out
 
 
