@@ -569,10 +569,18 @@ __device__ __forceinline__ int vq_tail_pd_lo(int od) { const int c = (od > 0 ? o
 __device__ __forceinline__ int vq_tail_pd_hi(int od) { const int c = (od < 7 ? od + 1 : 7) >> 1; return c < 3 ? c + 1 : 3; }
 __device__ __forceinline__ bool vq_tail_plane_needs(int od, int pd) { return pd >= vq_tail_pd_lo(od) && pd <= vq_tail_pd_hi(od); }
 
+// WMODE: how the next step's weight pieces travel global -> register -> LDS.  0 (the library): one piece per few groups, requested at
+// the group's start and stored after its MFMAs.  1: all of the step's pieces requested at the step's start, before the step's
+// activation re-loads, and stored at its end (NPW x 4 registers more) — built on the suspicion that the in-order return of
+// vector-memory operations made every store wait for an activation re-load behind an L2 miss; the waits turned out to be exact
+// counts that leave the younger re-loads in flight either way, and the two modes time the same (profiles/r04_ablate_folded_tail.txt).
+// ABL (tools/ablate/conv_mfma32_ablate.hip only): 1 no barriers, 2 no weight streaming, 4 no LDS A-fragment reads, 8 no activation
+// re-loads, 16 no input transform, 32 no epilogue, 64 no row-blocked totals, 128 no MFMAs
 template <int CIN, int COUT, int NPI, int NPO, int NW, bool STREAM, int KWG, int INMODE, int GIN, bool RESID, int GOUT,
-          bool CSUM, int OUTMODE>
+          bool CSUM, int OUTMODE, int ABL = 0, int WMODE = 0>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const int4* __restrict__ steps)
 {
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* lds = (f32x4*)smem_raw;
     constexpr int NU = CIN / 8, NMT = COUT / 32, NK = NU * NMT;
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
         bool last;
         do {
             const int4 en2 = steps[si + 2 < NS ? si + 2 : NS - 1];   // consumed one step later
-            __syncthreads();   // every wave's pieces of W(s) are in LDS; every wave done reading W(s-1)
+            if (!(ABL & 1)) __syncthreads();   // every wave's pieces of W(s) are in LDS; every wave done reading W(s-1)
             const f32x4* wl = lds + (si & 1) * WSTEP + lane;
             // OUTMODE 2 (folded tail): cout tiles 0,1 are the voxels of depth od = 2 po, tiles 2,3 those of od = 2 po + 1, and a voxel plane
             // only depends on the input planes pd in [pd_lo(od), pd_hi(od)] (two levels of 3-tap receptive fields: od +-1 -> coarse cell
@@ -677,16 +685,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                 act_lo = vq_tail_plane_needs(2 * po, pd), act_hi = vq_tail_plane_needs(2 * po + 1, pd);
             }
             f32x4 a_nx = wl[0];
+            f32x4 wstep[WMODE == 1 ? NPW : 1];
+            if (WMODE == 1 && !(ABL & 2)) {
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) wstep[k] = ldw(en.y, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < NGR; ++g) {
                 const int kg = g / NU, u = g % NU;
                 f32x4 wnext[PPG];
 #pragma unroll
                 for (int jp = 0; jp < PPG; ++jp)
-                    if (piece_first(g) + jp < piece_first(g + 1)) wnext[jp] = ldw(en.y, piece_first(g) + jp);
+                    if (WMODE == 0 && !(ABL & 2) && piece_first(g) + jp < piece_first(g + 1)) wnext[jp] = ldw(en.y, piece_first(g) + jp);
                 __builtin_amdgcn_sched_barrier(0);   // requested here, a whole group ahead of the ds_write
                 f32x4 b = bn[kg][u];
-                if (INMODE == 1) {
+                if (ABL & 16) {
+                } else if (INMODE == 1) {
                     b.x = fmaxf(__builtin_fmaf(b.x, ta[u][0], tb[u][0]), 0.0f);
                     b.y = fmaxf(__builtin_fmaf(b.y, ta[u][1], tb[u][1]), 0.0f);
                     b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
@@ -700,21 +715,30 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
                     const f32x4 a = a_nx;
-                    if (g * NMT + mt + 1 < NGR * NMT) a_nx = wl[(g * NMT + mt + 1) * 64];   // LDS A fragment one group ahead of its MFMAs
+                    if (!(ABL & 4) && g * NMT + mt + 1 < NGR * NMT) a_nx = wl[(g * NMT + mt + 1) * 64];   // LDS A fragment one group ahead of its MFMAs
                     if (OUTMODE == 2 && NMT == 4 && !(mt < NMT / 2 ? act_lo : act_hi)) continue;   // (wave-uniform) structurally zero weights
+                    if (ABL & 128) {
+                        acc[mt][0] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                        continue;
+                    }
                     acc[mt] = mfma32(a.x, b.x, acc[mt]);
                     acc[mt] = mfma32(a.y, b.y, acc[mt]);
                     acc[mt] = mfma32(a.z, b.z, acc[mt]);
                     acc[mt] = mfma32(a.w, b.w, acc[mt]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                bn[kg][u] = ldx(en.x + kg, u);   // the next step's position, right after this one's last use (index clamped)
+                if (!(ABL & 8)) bn[kg][u] = ldx(en.x + kg, u);   // the next step's position, right after this one's last use (index clamped)
 #pragma unroll
                 for (int jp = 0; jp < PPG; ++jp)
-                    if (piece_first(g) + jp < piece_first(g + 1))
+                    if (WMODE == 0 && !(ABL & 2) && piece_first(g) + jp < piece_first(g + 1))
                         lds[((si + 1) & 1) * WSTEP + ((piece_first(g) + jp) * NW + wave) * 64 + lane] = wnext[jp];
             }
-            if (OUTMODE == 2 && (e.x & 3) == 3) {   // row complete (a slab's positions start and end on row boundaries)
+            if (WMODE == 1 && !(ABL & 2)) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) lds[((si + 1) & 1) * WSTEP + (k * NW + wave) * 64 + lane] = wstep[k];
+            }
+            if (OUTMODE == 2 && !(ABL & 64) && (e.x & 3) == 3) {   // row complete (a slab's positions start and end on row boundaries)
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -725,9 +749,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
             en = en2;
             ++si;
         } while (!last);
-        if (OUTMODE == 2) {
+        if (OUTMODE == 2 && !(ABL & 64)) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = tot[mt];
+        }
+        if (ABL & 32) {
+            float t = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) t += acc[mt][0] + acc[mt][15];
+            if (t == 12345.678f) A.out[threadIdx.x] = t;
+            continue;
         }
 
         // ---- epilogue for output position po ----
