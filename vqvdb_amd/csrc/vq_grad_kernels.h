@@ -1214,6 +1214,119 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_k(const float* __restrict__ 
     }
 }
 
+// The same in ONE launch (round 4).  On the data-gradient chain the three launches above cost 1.06 ms of a 4.6 ms step (2048 leaves per
+// rank, profiles/r04_training_step_timeline.txt): each reads x and da from HBM again, next to the weight gradients of the other stream.
+// Here a workgroup owns whole GroupNorm groups — (tile, QW channel quads, LW leaves) for ALL positions — and every thread keeps its PT
+// positions of (xh, gi) in registers between the reduction and the elementwise phase: x and da are read once.  The sums meet in LDS in a
+// fixed order (position ranges ascending), so the result does not depend on scheduling.  Per-(tile, channel, leaf) dgamma / dbeta
+// partials leave in gn_bwd_sums_k's layout (one position range) for gn_bwd_finish_k's channel reduction.
+//   C = 64: group = 2 quads, 512 threads;  C = 32: group = 1 quad, 256 threads;  C = 16: one quad (two groups of 2 or one of 4) and
+//   16 leaves per workgroup, 1024 threads.  Eight positions per thread everywhere; grid (tiles, 8).
+template <int C, int NP, int CPG, int QW, int LW, int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_fused_k(const float* __restrict__ x, const float* __restrict__ da, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ add, float* __restrict__ dx, float* __restrict__ dgam, float* __restrict__ dbet)
+{
+    constexpr int G = C / CPG, COLS = QW * LW, PS = NT / COLS, PT = NP / PS, NWV = NT / 64, RPW = 64 / COLS;
+    constexpr int NGL = CPG == 2 ? 2 : 1;            // groups a thread's four channels belong to
+    constexpr int NV = 2 * NGL + 8;                  // values a thread contributes: (S1, S2) per group, dgamma x4, dbeta x4
+    static_assert(PT * PS == NP && COLS * PS == NT && (COLS == 16 || COLS == 32 || COLS == 64), "thread mapping");
+    static_assert((C / 4 / QW) * (32 / LW) == 8, "gridDim.y = 8 units per tile");
+    static_assert(CPG == 2 || CPG == 4 || (CPG == 8 && QW == 2), "a workgroup owns whole groups");
+    constexpr float inv_n = 1.0f / (float)(CPG * NP);
+    __shared__ float red[NWV][COLS][NV];
+    __shared__ float gsum[COLS][2 * NGL];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int col = tid % COLS, ps = tid / COLS;
+    const int tile = blockIdx.x, unit = blockIdx.y;
+    const int q0 = LW == 32 ? unit * QW : unit >> 1, leaf0 = LW == 32 ? 0 : 16 * (unit & 1);
+    const int quad = q0 + col / LW, j = leaf0 + col % LW;
+    float mu[4], rs[4], ia[4], ib[4], gm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ch = 4 * quad + k, g = ch / CPG;
+        mu[k] = mean[((size_t)tile * G + g) * 32 + j];
+        rs[k] = rstd[((size_t)tile * G + g) * 32 + j];
+        gm[k] = gamma[ch];
+        ia[k] = rs[k] * gm[k];
+        ib[k] = __builtin_fmaf(-mu[k], ia[k], beta[ch]);
+    }
+    const size_t base = (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j + (size_t)(ps * PT) * (C / 4) * 32;
+    f32x4 xv[PT], dv[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) xv[i] = ((const f32x4*)x)[base + (size_t)i * (C / 4) * 32], dv[i] = ((const f32x4*)da)[base + (size_t)i * (C / 4) * 32];
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, ds[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xs[k] - mu[k]) * rs[k];
+            const float d = __builtin_fmaf(xs[k], ia[k], ib[k]) > 0.0f ? ds[k] : 0.0f;
+            const float gi = d * gm[k];
+            a1[k] += gi;
+            a2[k] = __builtin_fmaf(gi, xh, a2[k]);
+            dg[k] = __builtin_fmaf(d, xh, dg[k]);
+            db[k] += d;
+            xs[k] = xh, ds[k] = gi;   // kept for the elementwise phase
+        }
+        xv[i] = (f32x4){xs[0], xs[1], xs[2], xs[3]}, dv[i] = (f32x4){ds[0], ds[1], ds[2], ds[3]};
+    }
+    float v[NV];
+    if (CPG == 2) v[0] = a1[0] + a1[1], v[1] = a2[0] + a2[1], v[2] = a1[2] + a1[3], v[3] = a2[2] + a2[3];
+    else v[0] = (a1[0] + a1[1]) + (a1[2] + a1[3]), v[1] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[2 * NGL + k] = dg[k], v[2 * NGL + 4 + k] = db[k];
+    // the RPW position ranges of a wave that share a column: lanes COLS apart
+#pragma unroll
+    for (int m = COLS; m < 64; m <<= 1)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] += __shfl_xor(v[e], m, 64);
+    if ((tid & 63) < COLS) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) red[wave][col][e] = v[e];
+    }
+    __syncthreads();
+    // the column's totals over the position ranges (waves ascending), by one thread per column; dgamma / dbeta leave from here
+    if (tid < COLS) {
+        float tot[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) tot[e] = 0.0f;
+#pragma unroll 2
+        for (int w = 0; w < NWV; ++w)
+#pragma unroll
+            for (int e = 0; e < NV; ++e) tot[e] += red[w][col][e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dgam[((size_t)tile * C + 4 * quad + k) * 32 + j] = tot[2 * NGL + k];
+            dbet[((size_t)tile * C + 4 * quad + k) * 32 + j] = tot[2 * NGL + 4 + k];
+        }
+#pragma unroll
+        for (int e = 0; e < 2 * NGL; ++e) gsum[col][e] = tot[e];
+    }
+    __syncthreads();
+    float t1[NGL], t2[NGL];
+#pragma unroll
+    for (int g = 0; g < NGL; ++g) {
+        float s1 = gsum[col][2 * g], s2 = gsum[col][2 * g + 1];
+        if (CPG == 8) s1 += gsum[col ^ 32][2 * g], s2 += gsum[col ^ 32][2 * g + 1];   // the group's other quad (commutative: both quads get the same bits)
+        t1[g] = s1 * inv_n, t2[g] = s2 * inv_n;
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const float xh[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, gi[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = CPG == 2 ? k >> 1 : 0;
+            r[k] = rs[k] * (gi[k] - t1[g] - xh[k] * t2[g]);
+        }
+        f32x4 out = {r[0], r[1], r[2], r[3]};
+        if (add) out = out + ((const f32x4*)add)[base + (size_t)i * (C / 4) * 32];
+        ((f32x4*)dx)[base + (size_t)i * (C / 4) * 32] = out;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ChannelAttention backward (y = x * g, g = sigmoid(W2 relu(W0 mean_pos(x))), VQVAE_v2.py:213-228), one wave per tile.
 // dyA (+ dyB): gradient(s) wrt y.  dx = dy*g + dm/NP;  partial weight gradients summed over the tile's leaves:

@@ -224,6 +224,8 @@ struct vqhip_codec {
     char* ft_part = nullptr;                                       // partial-gradient scratch
     size_t ft_part_bytes = 0;
     bool full_training = false, keep_y1 = false, weights_stale = false;
+    bool train_gn_fused = true;      // GroupNorm + ReLU backward as one pass per layer (gn_bwd_fused_k); VQHIP_TRAIN_GNBWD=split: sums + finish + apply
+    bool train_bias_main = true;     // bias gradients on the data-gradient stream (VQHIP_TRAIN_BIAS=side: beside the weight gradients)
     bool train_side_stream = true;   // training backward: weight / bias gradients on a second stream beside the data-gradient chain (VQHIP_TRAIN_STREAMS=1: one stream)
     hipStream_t ft_side = nullptr;
     std::vector<hipEvent_t> ft_ev;   // fork / join events of the side stream, reused every step
@@ -1722,6 +1724,8 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD")) c->train_wgrad_rows = std::strcmp(e, "pairs") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_STREAMS")) c->train_side_stream = std::strcmp(e, "1") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_GNBWD")) c->train_gn_fused = std::strcmp(e, "split") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_BIAS")) c->train_bias_main = std::strcmp(e, "side") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "gather") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
