@@ -158,6 +158,31 @@ def test_weight_gradient_kernel_families_agree(weights, monkeypatch):
                 assert np.array_equal(a[k], b[k]), (n, k)
 
 
+def test_groupnorm_backward_paths_agree(weights, monkeypatch):
+    """Round 4 replaced the three launches of GroupNorm + ReLU backward (sums, finish, apply) by one pass per layer (gn_bwd_fused_k: a
+    workgroup owns whole groups of a tile and keeps its elements in registers between the reduction and the elementwise phase) and moved
+    the bias sums onto the data-gradient stream; VQHIP_TRAIN_GNBWD=split / VQHIP_TRAIN_BIAS=side keep the old arrangement.  The group
+    sums are added in another order, so every parameter gradient must agree to 2e-6 of its tensor's maximum (measured 2e-7 .. 5e-7; ragged tile, three tiles
+    with a ragged last one, 1000 leaves); where the bias sums run changes no bit."""
+    def grads(env, n):
+        for k in ("VQHIP_TRAIN_GNBWD", "VQHIP_TRAIN_BIAS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = HipCodec(weightpack.dumps(weights))
+        c.fulltrain_begin()
+        g = _hip_grads(c, weights, synth.make_leaves(n, seed=700 + n))
+        c.close()
+        return g
+    for n in (7, 65, 1000):
+        fused, split, side = grads({}, n), grads({"VQHIP_TRAIN_GNBWD": "split"}, n), grads({"VQHIP_TRAIN_BIAS": "side"}, n)
+        worst = max((float(np.abs(fused[k] - split[k]).max() / max(np.abs(split[k]).max(), 1e-30)), k) for k in fused)
+        print(n, worst)
+        assert worst[0] < 2e-6, (n, worst)
+        for k in fused:
+            assert np.array_equal(fused[k], side[k]), (n, k)
+
+
 @pytest.mark.parametrize("folded", [True, False])
 def test_decoder_gradients_match_autograd(fcodec, ref_grads, weights, folded):
     """folded = the default: the tail (up_conv -> PixelShuffle3D -> final) as one folded operator, forward and backward, its parameter
