@@ -90,6 +90,15 @@ int main()
     run("16x16x4, 2 chains, 1 wave/SIMD", mfma_k<2, false>, 256, 2, false, d);
     run("16x16x4, 3 chains, 1 wave/SIMD", mfma_k<3, false>, 256, 3, false, d);
     run("16x16x4, 4 chains, 1 wave/SIMD", mfma_k<4, false>, 256, 4, false, d);
+    // the kernels of this library interleave 2-4 accumulators at 2-4 waves per SIMD: does the second wave fill the dependent-issue gap?
+    run("16x16x4, 2 chains, 2 waves/SIMD", mfma_k<2, false>, 512, 2, false, d);
+    run("16x16x4, 2 chains, 4 waves/SIMD", mfma_k<2, false>, 1024, 2, false, d);
+    run("16x16x4, 3 chains, 2 waves/SIMD", mfma_k<3, false>, 512, 3, false, d);
+    run("16x16x4, 3 chains, 4 waves/SIMD", mfma_k<3, false>, 1024, 3, false, d);
+    run("16x16x4, 4 chains, 2 waves/SIMD", mfma_k<4, false>, 512, 4, false, d);
+    run("16x16x4, 4 chains, 4 waves/SIMD", mfma_k<4, false>, 1024, 4, false, d);
+    run("16x16x4, 6 chains, 2 waves/SIMD", mfma_k<6, false>, 512, 6, false, d);
+    run("16x16x4, 16 chains, 2 waves/SIMD", mfma_k<16, false>, 512, 16, false, d);
     run("32x32x2, 4 independent acc, 1 wave/SIMD", mfma_k<4, true>, 256, 4, true, d);
     run("32x32x2, 4 independent acc, 2 waves/SIMD", mfma_k<4, true>, 512, 4, true, d);
     run("32x32x2, 1 dependent chain, 1 wave/SIMD", mfma_k<1, true>, 256, 1, true, d);
