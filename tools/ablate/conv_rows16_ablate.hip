@@ -75,8 +75,11 @@ int main()
 #define R(ABL) run("dec res64 conv1, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL>, A, steps, nt)
     // ABL bits: 1 no barriers, 2 no weight streaming, 4 no LDS A reads, 8 no activation re-loads, 16 no GN transform, 32 no epilogue
     R(0); R(1); R(2); R(8); R(32); R(63);
+#define RK2(ABL) run("dec res64 conv1, kw-outer, 2 outputs per run, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL, true, 2>, A, steps, nt)
+#define RK4(ABL) run("dec res64 conv1, kw-outer, 4 outputs per run, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL, true, 4>, A, steps, nt)
 #define RK(ABL) run("dec res64 conv1, kw-outer, ABL " #ABL, conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false, 1, false, 8, false, ABL, true>, A, steps, nt)
     RK(0); RK(128); RK(8); RK(16); RK(32); RK(64); RK(63);
+    RK(0); RK2(0); RK4(0); RK(0); RK2(0); RK4(0); RK2(63); RK4(63);
     {   // encoder res32 conv1: 32 -> 32 k3 @4^3, weights LDS-resident (108 KB), 16 waves
         std::vector<int> t2 = steps_rows(4, 4, 3, 1, 1);
         ConvArgs B = A;

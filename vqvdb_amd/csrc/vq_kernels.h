@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) void tail_small16_k(ConvArgs A)
 // -> 91-93 % at 2.38 GHz (buffer addressing, REGW, lazy arrival).
 // wfrag[((tap*CBN + cb)*MTN + mt)*64 + lane][i] = W[16mt + (lane&15)][16cb + 4(lane>>4) + i][tap];  bias: plain [COUT].
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0, bool KWO = false>
+template <int CIN, int COUT, int SI, int SO, int KS, int STRIDE, int PAD, int INMODE, bool RESID, int GOUT, bool CSUM, bool RESIDENT = false, int MSPLIT = 1, bool PF2 = false, int NWV = 8, bool PARTS = false, int ABL = 0, bool KWO = false, int OWI = 1>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const int4* __restrict__ steps)
 {
     static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
@@ -1214,34 +1214,44 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
                             read_group(g, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);   // requests first, a whole group ahead of their use (not sunk next to it)
+                        static_assert(SO % OWI == 0, "outputs interleaved per MFMA run");
 #pragma unroll
-                        for (int ow = 0; ow < SO; ++ow) {
-                            const int iw = ow * STRIDE - PAD + kw;
-                            if (iw < 0 || iw >= SI) continue;
-                            // k outer, cout tile inner: consecutive MFMAs go to different accumulators (each accumulator still sees its
-                            // k steps in ascending order), so neither the dependent-issue latency nor an instruction the scheduler
-                            // drops between two of them lands between an MFMA and the one that needs its result
+                        for (int ow0 = 0; ow0 < SO; ow0 += OWI) {
+                            // k outer, (output, cout tile) inner: consecutive MFMAs go to different accumulators (each accumulator still sees
+                            // its k steps in ascending order), so neither the dependent-issue latency nor an instruction the scheduler
+                            // drops between two of them lands between an MFMA and the one that needs its result.  OWI outputs share a
+                            // run: MTL x OWI accumulators in rotation (4 -> 8 at OWI = 2: profiles/r04_mfma_chain_depth.txt)
 #pragma unroll
                             for (int c2 = 0; c2 < CP; ++c2)
 #pragma unroll
                                 for (int k = 0; k < 4; ++k)
 #pragma unroll
-                                    for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = mfma16(a[set][c2][mt][k], xr[iw][cbp + c2][k], acc[ow][mt]);
+                                    for (int oo = 0; oo < OWI; ++oo) {
+                                        const int ow = ow0 + oo, iw = ow * STRIDE - PAD + kw;
+                                        if (iw < 0 || iw >= SI) continue;
+#pragma unroll
+                                        for (int mt = 0; mt < MTL; ++mt) acc[ow][mt] = mfma16(a[set][c2][mt][k], xr[iw][cbp + c2][k], acc[ow][mt]);
+                                    }
                             // was this kw the position's last tap of the row?  Then these channel blocks are re-loaded for the next step
                             // right here, between the outputs' MFMA runs (not all of a group's re-loads in one burst at its end: the
                             // eight waves of a workgroup run in step, and a burst of requests stalls their issue)
-                            int lastkw = -1;
 #pragma unroll
-                            for (int k2 = 0; k2 < KS; ++k2) {
-                                const int num = iw + PAD - k2;
-                                if (num >= 0 && num % STRIDE == 0 && num / STRIDE < SO) lastkw = k2;
-                            }
-                            if (lastkw == kw && !(ABL & 8)) {
-                                __builtin_amdgcn_sched_barrier(0);
+                            for (int oo = 0; oo < OWI; ++oo) {
+                                const int ow = ow0 + oo, iw = ow * STRIDE - PAD + kw;
+                                if (iw < 0 || iw >= SI) continue;
+                                int lastkw = -1;
 #pragma unroll
-                                for (int c2 = 0; c2 < CP; ++c2)
-                                    xr[iw][cbp + c2] = ldx(en.x + iw, (cbp + c2));   // next step's row (index clamped)
-                                __builtin_amdgcn_sched_barrier(0);
+                                for (int k2 = 0; k2 < KS; ++k2) {
+                                    const int num = iw + PAD - k2;
+                                    if (num >= 0 && num % STRIDE == 0 && num / STRIDE < SO) lastkw = k2;
+                                }
+                                if (lastkw == kw && !(ABL & 8)) {
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int c2 = 0; c2 < CP; ++c2)
+                                        xr[iw][cbp + c2] = ldx(en.x + iw, (cbp + c2));   // next step's row (index clamped)
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
