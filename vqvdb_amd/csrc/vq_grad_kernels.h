@@ -1339,13 +1339,14 @@ __global__ __launch_bounds__(64 * C / 8) void se_bwd_k(const float* __restrict__
 {
     // C/8 waves; wave w owns channel quads 2w, 2w+1 (lane half h -> quad 2w+h) in the position sweeps; wave 0 does the per-leaf MLP
     constexpr int R = C / 4;
-    __shared__ float dgl[C][32], gl[C][32], dml[C][32], hl[R][32], dhl[R][32];
+    __shared__ float dgl[C][32], gl[C][32], dml[C][32], hl[R][32], dhl[R][32], ml[C][32];
     const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const int quad = 2 * wave + h;
     const size_t base = (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
     {
         f32x4 s = {0, 0, 0, 0};
-#pragma unroll 4
+        // (sixteen positions in flight per thread: the sweep is a chain of HBM round trips, four at a time it took a third of the kernel)
+#pragma unroll 16
         for (int p = 0; p < NP; ++p) {
             const size_t o = base + (size_t)p * (C / 4) * 32;
             f32x4 d = ((const f32x4*)dyA)[o];
@@ -1354,6 +1355,9 @@ __global__ __launch_bounds__(64 * C / 8) void se_bwd_k(const float* __restrict__
         }
         dgl[4 * quad + 0][j] = s.x, dgl[4 * quad + 1][j] = s.y, dgl[4 * quad + 2][j] = s.z, dgl[4 * quad + 3][j] = s.w;
     }
+    // the tile's channel means, once (the weight-gradient loop below read csum from global memory inside its leaf loop: 32 dependent
+    // round trips per entry)
+    for (int e = threadIdx.x; e < C * 32; e += 64 * C / 8) ml[e >> 5][e & 31] = csum[(size_t)tile * C * 32 + e] * (1.0f / (float)NP);
     __syncthreads();
     const float* cs = csum + (size_t)tile * C * 32 + j;
     if (wave == 0) {
@@ -1394,7 +1398,7 @@ __global__ __launch_bounds__(64 * C / 8) void se_bwd_k(const float* __restrict__
         float v2 = 0.0f, v0 = 0.0f;
         for (int jj = 0; jj < 32; ++jj) {
             v2 = __builtin_fmaf(dgl[c2][jj], hl[r2][jj], v2);
-            v0 = __builtin_fmaf(dhl[r0][jj], csum[((size_t)tile * C + c0) * 32 + jj] * (1.0f / (float)NP), v0);
+            v0 = __builtin_fmaf(dhl[r0][jj], ml[c0][jj], v0);
         }
         pfc2[(size_t)tile * C * R + e] = v2;
         pfc0[(size_t)tile * C * R + e] = v0;
@@ -1402,7 +1406,7 @@ __global__ __launch_bounds__(64 * C / 8) void se_bwd_k(const float* __restrict__
     {
         const f32x4 g4 = {gl[4 * quad][j], gl[4 * quad + 1][j], gl[4 * quad + 2][j], gl[4 * quad + 3][j]};
         const f32x4 m4 = {dml[4 * quad][j], dml[4 * quad + 1][j], dml[4 * quad + 2][j], dml[4 * quad + 3][j]};
-#pragma unroll 4
+#pragma unroll 16
         for (int p = 0; p < NP; ++p) {
             const size_t o = base + (size_t)p * (C / 4) * 32;
             f32x4 d = ((const f32x4*)dyA)[o];
