@@ -141,6 +141,16 @@ __device__ __forceinline__ void gn_finish(double S, double Q, double inv_n, floa
     rstd = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// relu(v * a + b) on four channels of one element: the multiply-adds as two packed fmas (v_pk_fma_f32: two IEEE fmas per vector-ALU
+// slot — the same roundings as four fmaf, half the issue slots on the pipe the MFMAs share); v_max_f32 has no packed form
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 gn_relu4(f32x4 v, f32x4 a, f32x4 b)
+{
+    const f32x2 lo = __builtin_elementwise_fma((f32x2){v.x, v.y}, (f32x2){a.x, a.y}, (f32x2){b.x, b.y});
+    const f32x2 hi = __builtin_elementwise_fma((f32x2){v.z, v.w}, (f32x2){a.z, a.w}, (f32x2){b.z, b.w});
+    return (f32x4){fmaxf(lo.x, 0.0f), fmaxf(lo.y, 0.0f), fmaxf(hi.x, 0.0f), fmaxf(hi.y, 0.0f)};
+}
+
 __device__ __forceinline__ double shfl_xor32_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);

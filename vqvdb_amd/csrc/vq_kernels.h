@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     if (!active) half = 2 * A.n_tiles - 1;
     const int tile = half >> 1;
     const int jj = (lane & 15) + 16 * (half & 1), q4 = lane >> 4;
-    float ta[INMODE == 1 ? CBN : 1][4], tb[INMODE == 1 ? CBN : 1][4];   // input channel 16cb + 4q4 + i, GroupNorm(8, CIN)
+    f32x4 ta[INMODE == 1 ? CBN : 1], tb[INMODE == 1 ? CBN : 1];   // input channel 16cb + 4q4 + i, GroupNorm(8, CIN)
     if (INMODE == 1) {
 #pragma unroll
         for (int cb = 0; cb < CBN; ++cb)
@@ -1119,11 +1119,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_rows16_k(ConvArgs A, const i
     // pipe idle, both waves of a SIMD at once because the barrier keeps them in step)
     auto arrive = [&](int iw, int cb) {
         f32x4 v = xr[iw][cb];
-        v.x = fmaxf(__builtin_fmaf(v.x, ta[cb][0], tb[cb][0]), 0.0f);
-        v.y = fmaxf(__builtin_fmaf(v.y, ta[cb][1], tb[cb][1]), 0.0f);
-        v.z = fmaxf(__builtin_fmaf(v.z, ta[cb][2], tb[cb][2]), 0.0f);
-        v.w = fmaxf(__builtin_fmaf(v.w, ta[cb][3], tb[cb][3]), 0.0f);
-        xr[iw][cb] = v;
+        xr[iw][cb] = gn_relu4(v, ta[cb], tb[cb]);
     };
     for (int row = g0; row < g1; ++row) {
         f32x4 acc[SO][MTL];
