@@ -707,10 +707,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
                     b.z = fmaxf(__builtin_fmaf(b.z, ta[u][2], tb[u][2]), 0.0f);
                     b.w = fmaxf(__builtin_fmaf(b.w, ta[u][3], tb[u][3]), 0.0f);
                 } else if (INMODE == 2) {
-                    b.x = b.x * ta[u][0];
-                    b.y = b.y * ta[u][1];
-                    b.z = b.z * ta[u][2];
-                    b.w = b.w * ta[u][3];
+                    b = b * (f32x4){ta[u][0], ta[u][1], ta[u][2], ta[u][3]};   // (two packed multiplies where the gates sit in register pairs)
                 }
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
@@ -1481,7 +1478,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
     const int tile = blockIdx.x * NW + wave;
     if (tile >= A.n_tiles) return;
     const int j = lane & 31, q = lane >> 5;
-    float gate[4][4];
+    f32x4 gate[4];   // (vectors: the gate multiply below is two packed multiplies per float4)
     if (A.se_gate) {   // (uniform) split launches: every position range would repeat the same prologue
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -1508,12 +1505,7 @@ __global__ __launch_bounds__(NW * 64, 4) void vq_folded_k(VqArgs A)
     for (int p = p0; p < p1; ++p) {
         f32x4 b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            b[u].x = bn[u].x * gate[u][0];
-            b[u].y = bn[u].y * gate[u][1];
-            b[u].z = bn[u].z * gate[u][2];
-            b[u].w = bn[u].w * gate[u][3];
-        }
+        for (int u = 0; u < 4; ++u) b[u] = bn[u] * gate[u];
         const int pn = p < 63 ? p + 1 : 63;
 #pragma unroll
         for (int u = 0; u < 4; ++u) bn[u] = in4[((size_t)pn * 8 + 2 * u) * 32];
