@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
     const bool has_out = A.out != nullptr;
     const vq_buf outb = buf_of(has_out ? (const f32x4*)A.out + (size_t)tile * 512 * 4 * 32 : (const f32x4*)A.in);
     const unsigned lane_o = (unsigned)(q4 * 32 + jj) * 16u;
-    float ia[2][4], ib[2][4];  // MODE 1: GroupNorm(4,16) of y1, group = q4 (this lane's 4 couts)
+    f32x4 ia[2], ib[2];  // MODE 1: GroupNorm(4,16) of y1, group = q4 (this lane's 4 couts)
     if (MODE == 1) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
@@ -269,10 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
                     st[sb][0].add(v.z);
                     st[sb][0].add(v.w);
                 } else {
-                    v.x = fmaxf(__builtin_fmaf(v.x, ia[sb][0], ib[sb][0]), 0.0f);
-                    v.y = fmaxf(__builtin_fmaf(v.y, ia[sb][1], ib[sb][1]), 0.0f);
-                    v.z = fmaxf(__builtin_fmaf(v.z, ia[sb][2], ib[sb][2]), 0.0f);
-                    v.w = fmaxf(__builtin_fmaf(v.w, ia[sb][3], ib[sb][3]), 0.0f);
+                    v = gn_relu4(v, ia[sb], ib[sb]);   // (packed fmas: vq_device.h)
                     // streaming (nontemporal) store: the 2.1 GB of a1 are read by the next kernel from HBM anyway, and a plain store's
                     // write-allocate traffic through L2 made this pass store-bound (0.65 -> 0.45 ms)
                     if (!(ABL & 8)) buf_st16_nt(v, outb, lane_o, (unsigned)((row * 8 + ow) * 128 + 16 * sb) * 16u);
