@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) pm[cb] = buf_ld4(mb, (unsigned)((4 * cb + q4) * 32 + jj) * 4u, 0), pr[cb] = buf_ld4(rb, (unsigned)((4 * cb + q4) * 32 + jj) * 4u, 0);
     };
-    f32x4 ia[2], ib[2];
+    float ia[2][4], ib[2][4];
     auto write_plane = [&](int P) __attribute__((always_inline)) {
         if ((P & 3) == 0) {
 #pragma unroll
@@ -98,7 +98,12 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int cb = k & 1;
-            dst[((pos0 + (k >> 1)) * 8 + 4 * cb) * 16] = gn_relu4(pf[k], ia[cb], ib[cb]);   // (packed fmas: vq_device.h)
+            f32x4 v = pf[k];
+            v.x = fmaxf(__builtin_fmaf(v.x, ia[cb][0], ib[cb][0]), 0.0f);
+            v.y = fmaxf(__builtin_fmaf(v.y, ia[cb][1], ib[cb][1]), 0.0f);
+            v.z = fmaxf(__builtin_fmaf(v.z, ia[cb][2], ib[cb][2]), 0.0f);
+            v.w = fmaxf(__builtin_fmaf(v.w, ia[cb][3], ib[cb][3]), 0.0f);
+            dst[((pos0 + (k >> 1)) * 8 + 4 * cb) * 16] = v;
         }
     };
 

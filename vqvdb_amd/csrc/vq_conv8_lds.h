@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
             pm1 = A.in_mean[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj], pr1 = A.in_rstd[((size_t)tile * 8 + 2 * q4 + 1) * 32 + jj];
         }
     };
-    f32x4 ia, ib;   // GroupNorm scale / shift of this lane's channel quad for the half tile being staged
+    float ia[4], ib[4];   // GroupNorm scale / shift of this lane's channel quad for the half tile being staged
     auto write_plane = [&](int P) {   // relu(GroupNorm(x)) once per element, then into slot P & 1
         if (!loader) return;   // (wave-uniform)
         if ((P & 7) == 0) {   // (wave-uniform) first plane of a half tile: its statistics arrived with this plane's prefetch
@@ -96,7 +96,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv8_lds_k(ConvArgs A)
         }
         f32x4* dst = slots + (P & 1) * 4096 + (lbase * 4 + q4) * 16 + j16;
 #pragma unroll
-        for (int k = 0; k < LPOS; ++k) dst[k * 4 * 16] = gn_relu4(pf[k], ia, ib);   // (packed fmas: vq_device.h)
+        for (int k = 0; k < LPOS; ++k) {
+            f32x4 v = pf[k];
+            v.x = fmaxf(__builtin_fmaf(v.x, ia[0], ib[0]), 0.0f);
+            v.y = fmaxf(__builtin_fmaf(v.y, ia[1], ib[1]), 0.0f);
+            v.z = fmaxf(__builtin_fmaf(v.z, ia[2], ib[2]), 0.0f);
+            v.w = fmaxf(__builtin_fmaf(v.w, ia[3], ib[3]), 0.0f);
+            dst[k * 4 * 16] = v;
+        }
     };
 
     f32x4 acc[OWN];
