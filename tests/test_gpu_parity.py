@@ -493,7 +493,7 @@ def test_large_path_kernel_variants_agree(pack, oracle, monkeypatch):
     encoder intermediates, and the oracle's on a sample."""
     leaves = np.concatenate([synth.make_leaves(2200, seed=31), synth.sparse_leaves(300, seed=32), synth.edge_leaves()])
     ref_idx = ref_rec = None
-    for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}, {"VQHIP_STEM": "gather"}, {"VQHIP_CONV4": "rows"},
+    for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}, {"VQHIP_STEM": "gather"}, {"VQHIP_FIRST": "steps"}, {"VQHIP_FIRST": "roll0"}, {"VQHIP_CONV4": "rows"},
                 {"VQHIP_DOWN": "rows"}, {"VQHIP_CONV4": "rows", "VQHIP_DOWN": "rows"}):
         for k in ("VQHIP_CONV8", "VQHIP_STEM", "VQHIP_CONV4", "VQHIP_DOWN"):
             monkeypatch.delenv(k, raising=False)

@@ -29,6 +29,7 @@
 #include "vq_conv8_lds.h"
 #include "vq_stem_taps.h"
 #include "vq_conv4_lds.h"
+#include "vq_first_roll.h"
 #include "vq_convdown_lds.h"
 #include "vq_train_kernels.h"
 #include "vq_grad_kernels.h"
@@ -173,6 +174,8 @@ struct vqhip_codec {
     bool conv8_w16 = true;   // ... with 16 waves (one half row each; a half row is a statistics block); VQHIP_CONV8=w8 selects 8 (one row each)
     bool convdown_lds = true;   // down conv of large passes: input planes streamed through LDS once, weights from L1 / L2 (vq_convdown_lds.h); VQHIP_DOWN=rows selects the row kernel (input re-fetched 3.06x)
     bool conv4_lds = true;   // 32-channel 4^3 convs of large passes: input planes in an LDS ring, weights straight from L1 / L2 (vq_conv4_lds.h); VQHIP_CONV4=rows selects the row kernel (weights LDS-resident, every input row re-fetched 6.25x)
+    bool first_roll_stats = false;   // ... for the statistics pass too (VQHIP_FIRST=roll0; measured slower)
+    bool first_roll = true;  // first conv of large passes, normalising pass: rolling row window in registers (vq_first_roll.h); VQHIP_FIRST=steps selects conv_first_k ((row, kd) steps, nine row loads per output row)
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
 
@@ -1164,10 +1167,20 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
         ConvArgs A{};
         A.in = a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
         A.out_mean = S.y1m, A.out_rstd = S.y1r, A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
-        L.run("enc_conv_first_stats", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        // first_roll: a wave per 16-leaf sub-tile with a rolling 3 x 3 row window in registers (three row loads per output row instead of nine)
+        const int gq = (2 * nt + 3) / 4;
+        // (the normalising pass only: its stores compete with the loads — 0.458 -> 0.393 ms; the statistics pass runs 0.322 ms on the
+        // (row, kd) kernel and 0.353 ms with the window, whose plane starts it cannot hide; VQHIP_FIRST=roll0 selects that as well)
+        L.run("enc_conv_first_stats", [&] {
+            if (c->first_roll_stats) hipLaunchKernelGGL(conv_first_roll_k<0>, dim3(gq), dim3(256), 0, s, A);
+            else hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+        });
         A.out = a["e_a1"], A.in_mean = S.y1m, A.in_rstd = S.y1r, A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
         A.out_mean = S.a1m, A.out_rstd = S.a1r;
-        L.run("enc_conv_first_gn", [&] { hipLaunchKernelGGL(conv_first_k<1>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        L.run("enc_conv_first_gn", [&] {
+            if (c->first_roll) hipLaunchKernelGGL(conv_first_roll_k<1>, dim3(gq), dim3(256), 0, s, A);
+            else hipLaunchKernelGGL(conv_first_k<1>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+        });
     }
     {
         ConvArgs A{};
@@ -1717,6 +1730,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("VQHIP_DOWN")) c->convdown_lds = std::strcmp(e, "rows") != 0;
     if (const char* e = std::getenv("VQHIP_CONV4")) c->conv4_lds = std::strcmp(e, "rows") != 0;
+    if (const char* e = std::getenv("VQHIP_FIRST")) c->first_roll = std::strcmp(e, "steps") != 0, c->first_roll_stats = std::strcmp(e, "roll0") == 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
