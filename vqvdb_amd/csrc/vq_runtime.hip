@@ -1058,7 +1058,10 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         L.run("enc_conv_first_stats_s", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
         combine("enc_stats_y1", 4, 1.0 / 2048.0, S.y1m, S.y1r);
         A.out = a["e_a1"], A.in_mean = S.y1m, A.in_rstd = S.y1r, A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
-        L.run("enc_conv_first_gn_s", [&] { hipLaunchKernelGGL(conv_first_k<1>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        L.run("enc_conv_first_gn_s", [&] {   // (rolling row window: vq_first_roll.h)
+            if (c->first_roll) hipLaunchKernelGGL(conv_first_roll_k<1>, dim3((2 * nt + 3) / 4, psf), dim3(256), 0, s, A);
+            else hipLaunchKernelGGL(conv_first_k<1>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+        });
         combine("enc_stats_a1", 8, 1.0 / 1024.0, S.a1m, S.a1r);
     } else {
         ConvArgs A{};
