@@ -34,6 +34,7 @@
 #include "vq_train_kernels.h"
 #include "vq_grad_kernels.h"
 #include "vq_train_tail.h"
+#include "vq_tail_rows.h"
 
 namespace {
 
@@ -153,7 +154,10 @@ const std::map<std::string, KernelInfo>& kernel_info()
         // folded map really needs (884 736/leaf); the kernel issues (160 steps x 4 + 64 steps x 2 cout tiles) x 32 voxels x 64
         // channels = 1 572 864 MAC/leaf (round 3: the MFMAs of a voxel plane against input planes it cannot depend on are skipped;
         // 224 steps x 128 x 64 = 1 835 008 before)
-        {"dec_tail", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1572864}},
+        {"dec_tail_slab", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1572864}},
+        // round 5 (tail_rows16_k): 16-voxel tiles of two (od,oh) cells with one reach box: the structural zeros are skipped along D and H,
+        // 296 (tile, input row) pairs x 64 MFMAs of 1024 MACs per 16 leaves = 1 212 416 MAC/leaf (exact D x H: 1 179 648; useful 884 736)
+        {"dec_tail", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1212416}},
     };
     return m;
 }
@@ -168,6 +172,7 @@ struct vqhip_codec {
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: one kernel; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
     bool stem_taps = true;   // ... the (tap, code) table streamed through an LDS ring tap by tap (stem_taps_k, vq_stem_taps.h: 0.81 -> 0.57 ms); VQHIP_STEM=gather selects stem_fused_k (gather through the L1)
+    bool tail_rows = true;   // folded decoder tail of full chunks: 16-voxel tiles, zeros skipped along D and H (tail_rows16_k, vq_tail_rows.h); VQHIP_TAIL=slab selects conv_mfma32_k<OUTMODE 2> (depth only)
     int tail16_tiles = 48;   // small-batch folded tail on the 16x16x4 MFMA up to this many tiles (VQHIP_TAIL16_TILES; measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us)
     bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
     int vq_split = 2;        // position ranges per tile in the VQ search of full chunks (VQHIP_VQ_SPLIT)
@@ -637,7 +642,39 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
                                 frags16[((((step * 8 + mb) * 4 + uu) * 64) + lane) * 4 + e] = wc[((size_t)(d * 128 + 16 * mb + m) * 64 + p) * 64 + ch];
                             }
     }
+    // ... and as the weight stream of tail_rows16_k (vq_tail_rows.h): one 32 KB slice per phase (unit, pd, ph, pw) in the order the
+    // kernel walks them, a slice = the 4 KB blocks [uu 4][lane][e] of the tiles that input row feeds, dense, ascending tile id
+    std::vector<float> wrows((size_t)(TR_PHASES + 2) * (TR_SLICE / 4), 0.0f);   // (two slices of padding: the kernel copies two phases ahead)
+    {
+        size_t t = 0, tile_rows = 0;
+        for (int unit = 0; unit < 5; ++unit) {
+            const bool pair = unit >= 1 && unit <= 3;
+            const int od0 = unit == 0 ? 0 : unit == 4 ? 7 : 2 * unit - 1;
+            for (int pd = tr_lo(od0); pd <= tr_hi(od0); ++pd)
+                for (int ph = 0; ph < 4; ++ph) {
+                    const unsigned mask = tr_mask(pair, ph);
+                    tile_rows += tr_popc(mask);
+                    for (int pw = 0; pw < 4; ++pw, ++t) {
+                        const int p = (pd * 4 + ph) * 4 + pw;
+                        for (int i = 0; i < tr_popc(mask); ++i) {
+                            const int tid = tr_nth(mask, i), ca = tr_cell_a(pair, od0, tid), cb = tr_cell_b(pair, od0, tid);
+                            float* blk = &wrows[t * (TR_SLICE / 4) + (size_t)i * 1024];
+                            for (int uu = 0; uu < 4; ++uu)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int u = 2 * uu + (e >> 1), mf = e & 1, m = lane & 15, k = lane >> 4;
+                                        const int ch = 8 * u + 4 * (k & 1) + (k >> 1) + 2 * mf;
+                                        const int vox = (m < 8 ? ca : cb) * 8 + (m & 7);
+                                        blk[(uu * 64 + lane) * 4 + e] = wc[((size_t)vox * 64 + p) * 64 + ch];
+                                    }
+                        }
+                    }
+                }
+        }
+        if (t != TR_PHASES || tile_rows != TR_TILE_ROWS) return fail(c, VQHIP_ERR_MODEL, "folded tail: row schedule does not match tail_rows16_k");
+    }
     int rc;
+    if ((rc = upload(c, "tail.wrows", wrows))) return rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
     if ((rc = upload(c, "tail.w16", frags16))) return rc;
@@ -964,6 +1001,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, conv8_lds_k<true, false, 16, 0, false>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, k_stem_taps, LDS_STEM_TAPS))) return rc;
+    if ((rc = set_lds(c, tail_rows16_k<0>, LDS_TAIL_ROWS))) return rc;
     if ((rc = set_lds(c, conv_down_lds_k<0>, LDS_CONVDOWN))) return rc;
     if ((rc = set_lds(c, conv4_lds_k<false, true, false, 0, 1>, LDS_CONV4))) return rc;
     if ((rc = set_lds(c, conv4_lds_k<true, false, true, 0, 0>, LDS_CONV4))) return rc;
@@ -1399,7 +1437,12 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         A.in = a["d_x6"], A.out = d_out, A.wfrag = w["tail.w"], A.bias_frag = w["tail.b"];
         A.se_csum = a["csum"], A.se_fc0 = w["dfc0"], A.se_fc2 = w["dfc2"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0;
-        L.run("dec_tail", [&] { hipLaunchKernelGGL(k_dec_tail, dim3(g8), dim3(512), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
+        if (c->tail_rows) {
+            A.wfrag = w["tail.wrows"], A.bias_frag = w["tail.braw"];
+            L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_ROWS, s, A); });
+        } else {
+            L.run("dec_tail_slab", [&] { hipLaunchKernelGGL(k_dec_tail, dim3(g8), dim3(512), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
+        }
     }
     return L.rc;
 }
@@ -1736,6 +1779,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_FIRST")) c->first_roll = std::strcmp(e, "steps") != 0, c->first_roll_stats = std::strcmp(e, "roll0") == 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
+    if (const char* e = std::getenv("VQHIP_TAIL")) c->tail_rows = std::strcmp(e, "slab") != 0;
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;

@@ -1,0 +1,263 @@
+// vq_tail_rows.h — the folded decoder tail of full chunks (round 5): up_conv 64->256 k3 @4^3 -> PixelShuffle3D(2) -> final 32->1
+// k3 @8^3 -> sigmoid (python/VQVAE_v2.py:265-268,274-275,172-187) as ONE linear map 64ch@4^3 -> 1ch@8^3 (see build_folded_tail),
+// on the 16x16x4 MFMA with the structural zeros of the composite operator skipped along D AND H.
+//
+// Why another kernel.  An output voxel (od,oh,ow) reaches, per axis, the coarse cells of o-1..o+1 and their neighbours: 2,3,3,4,4,3,3,2
+// of the 4 input planes / rows / columns (0.75 per axis, 0.42 of the dense 2 097 152 MAC/leaf over three axes).  conv_mfma32_k<OUTMODE 2>
+// tiles M as 32 voxels = (od, four oh rows, 8 ow): the union of four rows' reach is everything, only depth can be skipped
+// (1 572 864 MAC/leaf issued).  Here an M tile is 16 voxels = TWO (od,oh) cells x 8 ow whose reach in (pd,ph) is the same box, so the
+// tile's MFMAs run over exactly the input rows (pd,ph) the box holds:
+//   * od in {1,2}, {3,4}, {5,6} pair up along depth (identical reach): tile oh = cells (od0,oh),(od0+1,oh)         — "pair" units
+//   * od = 0 and od = 7 have no partner in depth; their cells pair up along H: (1,2), (3,4), (5,6) and the two
+//     corner cells (0,7), whose reach in H is disjoint (the one tile that pays for rows it does not need)             — "single" units
+//   296 tile-rows x 64 MFMAs per 16 leaves = 1 212 416 MAC/leaf issued (exact D x H would be 288 tile-rows = 1 179 648: the four corner
+//   cells (od,oh) in {0,7}^2 have boxes no other cell shares; W cannot be skipped with all 8 ow of a cell in one tile).
+//
+// Arithmetic = the oracle's tail_apply, unchanged: per voxel the input rows of its planes ascending, the four positions of a W-row one
+// fmaf chain from zero (channels in P8 order), row sums added in row order.  A row outside the voxel's reach in H has all-zero
+// composite weights there: its chain is fmaf(0, x, .) = +0 for the finite activations a decoder produces, and tot + (+0) = tot
+// (tot is never -0: it starts at +0 and x + (-x) = +0), so not running the row is bit-identical to running it.
+//
+// Structure.  A wave owns a 16-leaf HALF tile; a workgroup = 8 waves (2 per SIMD) = 128 leaves behind one stream of weights.
+// Five units of output planes, od = {0}, {1,2}, {3,4}, {5,6}, {7}; a unit walks the input rows (pd in its reach, ph = 0..3) once:
+//   row = 4 phases (pw = 0..3); phase = the active tiles' 16 MFMAs each (K = 64 channels of one input position), tiles interleaved
+//   (3-4 accumulators in rotation), fragments of item j+2 requested from LDS when item j has issued (two register sets).
+//   The activations of a row sit in 64 registers (one dword per MFMA slot: the P8 order needs channel pairs (c, c+2), so dword
+//   loads, not the float4 the 32x32x2 kernel shares between two K slots), gated on arrival (ChannelAttention, v_pk_mul), re-loaded
+//   for the next row right after the phase that used them last.
+//   Weights: one 32 KB slice per phase (dense list of the active tiles' 4 KB blocks; laid out by the host in consumption order),
+//   global -> register -> LDS into a ring of three slices, written two phases ahead; ONE barrier per phase publishes slice t+1 and
+//   frees the slot of slice t-1, so the first fragments of the next phase are read BEFORE its barrier.
+// Everything inside a unit is static (the row's active tiles depend on ph only): exact s_waitcnt counts, no branches but the pd loop.
+#pragma once
+#include <utility>
+#include "vq_kernels.h"
+
+template <int... I, typename F>
+__device__ __forceinline__ void tr_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void tr_static_for(F&& f) { tr_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+constexpr int TR_SLICE = 8 * 4096;                                   // bytes per weight slice: up to 8 tile blocks of 4 KB (3..7 used)
+constexpr int TR_RING = 3;
+constexpr size_t LDS_TAIL_ROWS = (size_t)TR_RING * TR_SLICE;          // 96 KB
+constexpr int TR_PHASES = 224;                                        // (2 + 3 + 4 + 3 + 2 planes) x 4 rows x 4 positions
+constexpr int TR_TILE_ROWS = 296;                                     // (tile, input row) pairs that are issued: 64 MFMAs each per 16 leaves
+
+// reach of output coordinate o (0..7 at 8^3) in input coordinates (0..3 at 4^3): final taps o-1..o+1 -> coarse cells -> +-1 (clamped)
+constexpr int tr_lo(int o) { const int c = (o > 0 ? o - 1 : 0) >> 1; return c > 0 ? c - 1 : 0; }
+constexpr int tr_hi(int o) { const int c = (o < 7 ? o + 1 : 7) >> 1; return c < 3 ? c + 1 : 3; }
+// tiles of a unit that input row ph feeds.  Pair units: tile oh (0..7).  Single units: tile 0 = rows (1,2), 1 = (3,4), 2 = (5,6), 3 = (0,7).
+constexpr unsigned tr_pair_mask(int ph)
+{
+    unsigned m = 0;
+    for (int oh = 0; oh < 8; ++oh)
+        if (ph >= tr_lo(oh) && ph <= tr_hi(oh)) m |= 1u << oh;
+    return m;
+}
+constexpr unsigned tr_single_mask(int ph) { return (ph <= 2 ? 1u : 0u) | 2u | (ph >= 1 ? 4u : 0u) | 8u; }
+constexpr unsigned tr_mask(bool pair, int ph) { return pair ? tr_pair_mask(ph) : tr_single_mask(ph); }
+constexpr int tr_popc(unsigned m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
+constexpr int tr_nth(unsigned m, int i) { for (int b = 0; b < 32; ++b) if (m >> b & 1) { if (i == 0) return b; --i; } return -1; }
+// the two (od,oh) cells of tile `tid` of a unit whose first plane is od0: rows 0-7 of the tile = cell A, rows 8-15 = cell B
+constexpr int tr_cell_a(bool pair, int od0, int tid) { return pair ? od0 * 8 + tid : od0 * 8 + (tid == 3 ? 0 : 2 * tid + 1); }
+constexpr int tr_cell_b(bool pair, int od0, int tid) { return pair ? (od0 + 1) * 8 + tid : od0 * 8 + (tid == 3 ? 7 : 2 * tid + 2); }
+// items of a phase with N active tiles: N <= 4: one item per fragment group (4 groups of 4 MFMA slots), all tiles; else two items
+// per group (first ceil(N/2) tiles, rest).  Item j uses fragment register set j & 1.
+constexpr int tr_parts(int n) { return n > 4 ? 2 : 1; }
+constexpr int tr_part_lo(int n, int part) { return tr_parts(n) == 1 ? 0 : (part == 0 ? 0 : (n + 1) / 2); }
+constexpr int tr_part_hi(int n, int part) { return tr_parts(n) == 1 ? n : (part == 0 ? (n + 1) / 2 : n); }
+
+// ABL (tools/ablate/tail_rows_ablate.hip only): 1 no barriers, 2 no weight streaming, 4 no LDS fragment reads, 8 no activation re-loads,
+// 16 no gate multiply, 32 no epilogue, 128 no MFMAs
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
+{
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, k = lane >> 4;
+    int half = blockIdx.x * 8 + wave;
+    const bool active = half < 2 * A.n_tiles;
+    if (!active) half = 2 * A.n_tiles - 1;   // a wave without a half tile re-computes the last one (it carries its share of the weights)
+    const int tile = half >> 1, jj = 16 * (half & 1) + n;
+    const bool store = active && (int64_t)tile * 32 + jj < A.n_leaves;
+
+    // ---- ChannelAttention gates of this lane's 16 channels: MFMA slot s = 2u + mf holds channel 8u + 4(k&1) + (k>>1) + 2mf ----
+    f32x2 tg[8];
+    {
+        float hid[16], gall[64];
+        se_hidden<64>(A.se_csum + (size_t)tile * 64 * 32 + jj, A.se_fc0, hid);
+        se_gates<64>(hid, A.se_fc2, gall);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const int c0 = 8 * u + 2 * mf;
+                const float lo = (k >> 1) ? gall[c0 + 1] : gall[c0], hi = (k >> 1) ? gall[c0 + 5] : gall[c0 + 4];
+                tg[u][mf] = (k & 1) ? hi : lo;
+            }
+    }
+
+    // activations: element (pos, channel c, leaf jj) at pos*8192 + (c>>2)*512 + jj*16 + (c&3)*4 bytes of the tile
+    const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 64 * 16 * 32);
+    const unsigned lane_x = (unsigned)((k & 1) * 512 + jj * 16 + (k >> 1) * 4);
+    f32x2 B[4][8];   // [pw][u] = (slot 2u, slot 2u+1)
+    auto reload = [&](int pw, int pos) {
+        if (ABL & 8) return;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            B[pw][u][0] = buf_ld4(inb, lane_x + u * 1024, (unsigned)pos * 8192u);
+            B[pw][u][1] = buf_ld4(inb, lane_x + u * 1024 + 8, (unsigned)pos * 8192u);
+        }
+    };
+    // weights: slice t at t*TR_SLICE; this wave moves bytes [wave*4096, +4096) of every slice
+    const vq_buf wb = buf_of(A.wfrag);
+    const unsigned lane_w = (unsigned)lane * 16u;
+    f32x4* const lds_w = (f32x4*)(smem_raw + wave * 4096) + lane;   // + slot*TR_SLICE/16 + j*64
+    const f32x4* const lds_r = (const f32x4*)smem_raw + lane;       // + slot*TR_SLICE/16 + (tile i*4 + g)*64
+    const vq_buf outb = buf_of(A.out + (size_t)tile * 32 * 512);
+    const float* bias = A.bias_frag;   // plain per voxel [512]
+
+    int t = 0, sl = 0;   // phase (= slice) counter and t % 3
+    auto slot_of = [&](int ahead) { const int s = sl + ahead; return s >= TR_RING ? s - TR_RING : s; };
+
+    // ---- prologue: slices 0 and 1, the first row's activations ----
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_w[s * (TR_SLICE / 16) + j * 64] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(s * TR_SLICE + wave * 4096));
+#pragma unroll
+    for (int pw = 0; pw < 4; ++pw) reload(pw, pw);   // unit 0 starts at plane 0, row 0
+    __builtin_amdgcn_s_waitcnt(0x0f70);               // enter the loops with nothing in flight
+    __syncthreads();
+
+    f32x4 fa[2][4];   // A-fragment register sets (item j -> set j & 1)
+    // fragments of item `it` of a phase with active mask M, from ring slot `slot`
+    auto frag_req = [&](auto mc, auto itc, int slot) {
+        constexpr unsigned M = decltype(mc)::value;
+        constexpr int it = decltype(itc)::value;
+        constexpr int N = tr_popc(M), P = tr_parts(N), g = it / P, part = it % P;
+        if (ABL & 4) return;
+#pragma unroll
+        for (int i = tr_part_lo(N, part); i < tr_part_hi(N, part); ++i) fa[it & 1][i - tr_part_lo(N, part)] = lds_r[slot * (TR_SLICE / 16) + (i * 4 + g) * 64];
+    };
+
+    auto run_unit = [&](auto pair_c, const int od0, const int pd_lo, const int pd_hi, const int p_next_unit) {
+        constexpr bool PAIR = decltype(pair_c)::value;
+        constexpr int NT = PAIR ? 8 : 4;
+        f32x4 tot[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tot[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        // the unit's first phase: its slice was published by the previous barrier
+        frag_req(std::integral_constant<unsigned, tr_mask(PAIR, 0)>{}, std::integral_constant<int, 0>{}, sl);
+        frag_req(std::integral_constant<unsigned, tr_mask(PAIR, 0)>{}, std::integral_constant<int, 1>{}, sl);
+#pragma nounroll
+        for (int pd = pd_lo; pd <= pd_hi; ++pd) {
+            auto row = [&](auto phc) {
+                constexpr int PH = decltype(phc)::value;
+                constexpr unsigned MASK = tr_mask(PAIR, PH), NMASK = tr_mask(PAIR, (PH + 1) & 3);
+                constexpr int N = tr_popc(MASK), P = tr_parts(N), NI = 4 * P;
+                const int pcur = (pd * 4 + PH) * 4;
+                const int pnext = (PH == 3 && pd == pd_hi) ? p_next_unit : pcur + 4;
+                f32x4 acc[NT];
+                auto phase = [&](auto pwc) {
+                    constexpr int PW = decltype(pwc)::value;
+                    constexpr unsigned NEXT = PW < 3 ? MASK : NMASK;
+                    t = __builtin_amdgcn_readfirstlane(t), sl = __builtin_amdgcn_readfirstlane(sl);   // (loop-carried counters: keep them scalar, the slice offset is the loads' scalar offset)
+                    if (!(ABL & 1)) __syncthreads();   // slice t+1 visible to every wave; every wave is done with slice t-1's slot
+                    // this wave's share of slice t+2 (the stream is padded by two slices: no clamp)
+                    f32x4 wreg[4];
+                    if (!(ABL & 2)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 1024, (unsigned)((t + 2) * TR_SLICE + wave * 4096));
+                    }
+                    // gate the position that arrived a row ago
+                    if (!(ABL & 16)) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) B[PW][u] = B[PW][u] * tg[u];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    tr_static_for<NI>([&](auto itc) {
+                        constexpr int it = decltype(itc)::value;
+                        constexpr int g = it / P, part = it % P, i0 = tr_part_lo(N, part), i1 = tr_part_hi(N, part);
+                        tr_static_for<4>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value, s = 4 * g + e;
+                            tr_static_for<i1 - i0>([&](auto ic) {
+                                constexpr int i = i0 + decltype(ic)::value, tid = tr_nth(MASK, i);
+                                const float a = fa[it & 1][i - i0][e], b = B[PW][s >> 1][s & 1];
+                                if constexpr ((ABL & 128) != 0) {
+                                    if constexpr (PW == 0 && s == 0) acc[tid][0] = a * b;
+                                    else acc[tid][0] += a * b;
+                                } else if constexpr (PW == 0 && s == 0) {
+                                    acc[tid] = mfma16(a, b, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});   // a W-row's chain starts from zero
+                                } else {
+                                    acc[tid] = mfma16(a, b, acc[tid]);
+                                }
+                            });
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                        // item it+2 of this phase, or item (it+2-NI) of the next one (its slice is in the ring since the last barrier)
+                        if constexpr (it + 2 < NI) frag_req(std::integral_constant<unsigned, MASK>{}, std::integral_constant<int, it + 2>{}, sl);
+                        else frag_req(std::integral_constant<unsigned, NEXT>{}, std::integral_constant<int, it + 2 - NI>{}, slot_of(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    reload(PW, pnext + PW);   // the same position of the next row
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ABL & 2)) {
+                        const int ws = slot_of(2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lds_w[ws * (TR_SLICE / 16) + j * 64] = wreg[j];
+                    }
+                    ++t;
+                    sl = slot_of(1);
+                };
+                phase(std::integral_constant<int, 0>{});
+                phase(std::integral_constant<int, 1>{});
+                phase(std::integral_constant<int, 2>{});
+                phase(std::integral_constant<int, 3>{});
+                tr_static_for<N>([&](auto ic) {
+                    constexpr int tid = tr_nth(MASK, decltype(ic)::value);
+                    tot[tid] = tot[tid] + acc[tid];   // row sums in row order
+                });
+            };
+            row(std::integral_constant<int, 0>{});
+            row(std::integral_constant<int, 1>{});
+            row(std::integral_constant<int, 2>{});
+            row(std::integral_constant<int, 3>{});
+        }
+        // ---- epilogue: per-voxel bias, sigmoid, store into the caller's leaf-major [n][512] buffer (VQVAECodec.cpp:182-192) ----
+        if (ABL & 32) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) s += tot[i][0] + tot[i][3];
+            if (s == 12345.678f) A.out[threadIdx.x] = s;
+            return;
+        }
+#pragma unroll
+        for (int tid = 0; tid < NT; ++tid) {
+            // rows 4k .. 4k+3 of the tile: k < 2 cell A, else cell B; ow = 4(k&1) .. +3
+            const int ca = PAIR ? od0 * 8 + tid : od0 * 8 + (tid == 3 ? 0 : 2 * tid + 1);
+            const int cb = PAIR ? (od0 + 1) * 8 + tid : od0 * 8 + (tid == 3 ? 7 : 2 * tid + 2);
+            const int vox = (k < 2 ? ca : cb) * 8 + (k & 1) * 4;
+            const f32x4 bv = *(const f32x4*)(bias + vox);
+            f32x4 sg;
+            sg.x = vq_sigmoid(tot[tid].x + bv.x), sg.y = vq_sigmoid(tot[tid].y + bv.y);
+            sg.z = vq_sigmoid(tot[tid].z + bv.z), sg.w = vq_sigmoid(tot[tid].w + bv.w);
+            if (store) buf_st16(sg, outb, (unsigned)(jj * 512 + vox) * 4u, 0u);
+        }
+    };
+
+    // od0 / planes of the five units: {0}: 0..1, {1,2}: 0..2, {3,4}: 0..3, {5,6}: 1..3, {7}: 2..3; a unit's last row re-loads the
+    // first row of the next unit (the last unit: its own last row again)
+#pragma nounroll
+    for (int unit = 0; unit < 5; ++unit) {
+        const int od0 = unit == 0 ? 0 : unit == 4 ? 7 : 2 * unit - 1;
+        const int pd_lo = unit <= 2 ? 0 : unit - 2, pd_hi = unit >= 2 ? 3 : unit + 1;
+        const int nlo = unit + 1 <= 2 ? 0 : unit - 1;   // first plane of unit + 1
+        const int p_next_unit = unit < 4 ? nlo * 16 : 60;
+        if (unit == 0 || unit == 4) run_unit(std::false_type{}, od0, pd_lo, pd_hi, p_next_unit);
+        else run_unit(std::true_type{}, od0, pd_lo, pd_hi, p_next_unit);
+    }
+}
