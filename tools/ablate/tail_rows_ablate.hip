@@ -40,7 +40,7 @@ int main()
 {
     const int nt = 2048;
     float *in, *out, *w, *bias, *csum, *fc0, *fc2;
-    const size_t wn = (size_t)(TR_PHASES + 2) * (TR_SLICE / 4);
+    const size_t wn = (size_t)TR_STREAM_SLICES * (TR_SLICE / 4);
     hipMalloc(&in, (size_t)nt * 64 * 16 * 32 * 16), hipMalloc(&out, (size_t)nt * 32 * 512 * 4), hipMalloc(&w, wn * 4), hipMalloc(&bias, 512 * 4);
     hipMalloc(&csum, (size_t)nt * 64 * 32 * 4), hipMalloc(&fc0, 16 * 64 * 4), hipMalloc(&fc2, 64 * 16 * 4);
     fill(in, (size_t)nt * 64 * 16 * 32 * 4, 1), fill(w, wn, 2, -0.05f, 0.05f), fill(bias, 512, 3), fill(csum, (size_t)nt * 64 * 32, 4, -8.0f, 8.0f);

@@ -644,7 +644,7 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
     }
     // ... and as the weight stream of tail_rows16_k (vq_tail_rows.h): one 32 KB slice per phase (unit, pd, ph, pw) in the order the
     // kernel walks them, a slice = the 4 KB blocks [uu 4][lane][e] of the tiles that input row feeds, dense, ascending tile id
-    std::vector<float> wrows((size_t)(TR_PHASES + 2) * (TR_SLICE / 4), 0.0f);   // (two slices of padding: the kernel copies two phases ahead)
+    std::vector<float> wrows((size_t)TR_STREAM_SLICES * (TR_SLICE / 4), 0.0f);   // (padded: the kernel requests slices three phases ahead)
     {
         size_t t = 0, tile_rows = 0;
         for (int unit = 0; unit < 5; ++unit) {

@@ -26,8 +26,8 @@
 //   loads, not the float4 the 32x32x2 kernel shares between two K slots), gated on arrival (ChannelAttention, v_pk_mul), re-loaded
 //   for the next row right after the phase that used them last.
 //   Weights: one 32 KB slice per phase (dense list of the active tiles' 4 KB blocks; laid out by the host in consumption order),
-//   global -> register -> LDS into a ring of three slices, written two phases ahead; ONE barrier per phase publishes slice t+1 and
-//   frees the slot of slice t-1, so the first fragments of the next phase are read BEFORE its barrier.
+//   global -> register (one phase) -> LDS into a ring of three slices, written two phases ahead; ONE barrier per phase publishes
+//   slice t+1 and frees the slot of slice t-1, so the first fragments of the next phase are read BEFORE its barrier.
 // Everything inside a unit is static (the row's active tiles depend on ph only): exact s_waitcnt counts, no branches but the pd loop.
 #pragma once
 #include <utility>
@@ -42,6 +42,7 @@ constexpr int TR_SLICE = 8 * 4096;                                   // bytes pe
 constexpr int TR_RING = 3;
 constexpr size_t LDS_TAIL_ROWS = (size_t)TR_RING * TR_SLICE;          // 96 KB
 constexpr int TR_PHASES = 224;                                        // (2 + 3 + 4 + 3 + 2 planes) x 4 rows x 4 positions
+constexpr int TR_STREAM_SLICES = TR_PHASES + 3;                       // the kernel requests slices up to three phases ahead: padding
 constexpr int TR_TILE_ROWS = 296;                                     // (tile, input row) pairs that are issued: 64 MFMAs each per 16 leaves
 
 // reach of output coordinate o (0..7 at 8^3) in input coordinates (0..3 at 4^3): final taps o-1..o+1 -> coarse cells -> +-1 (clamped)
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
     const int tile = half >> 1, jj = 16 * (half & 1) + n;
     const bool store = active && (int64_t)tile * 32 + jj < A.n_leaves;
 
-    // ---- ChannelAttention gates of this lane's 16 channels: MFMA slot s = 2u + mf holds channel 8u + 4(k&1) + (k>>1) + 2mf ----
+    // ---- ChannelAttention gates of this lane's 16 channels.  MFMA slot s = 2u + mf holds channel 8u + 4(k&1) + (k>>1) + 2mf; the
+    // gates are applied BEFORE the lane swap below, i.e. to the channel pair (8u + 4(k&1) + 2(k>>1), +1) the lane loads ----
     f32x2 tg[8];
     {
         float hid[16], gall[64];
@@ -93,23 +95,32 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                const int c0 = 8 * u + 2 * mf;
-                const float lo = (k >> 1) ? gall[c0 + 1] : gall[c0], hi = (k >> 1) ? gall[c0 + 5] : gall[c0 + 4];
-                tg[u][mf] = (k & 1) ? hi : lo;
+            for (int e = 0; e < 2; ++e) {
+                const int c0 = 8 * u + e;
+                const float lo = (k >> 1) ? gall[c0 + 2] : gall[c0], hi = (k >> 1) ? gall[c0 + 6] : gall[c0 + 4];
+                tg[u][e] = (k & 1) ? hi : lo;
             }
     }
 
-    // activations: element (pos, channel c, leaf jj) at pos*8192 + (c>>2)*512 + jj*16 + (c&3)*4 bytes of the tile
+    // activations: element (pos, channel c, leaf jj) at pos*8192 + (c>>2)*512 + jj*16 + (c&3)*4 bytes of the tile.  A lane loads the
+    // channel PAIR (4(k&1) + 2(k>>1), +1) of octet u as one dwordx2; it needs (4(k&1) + (k>>1), +2): lanes L and L+32 (same leaf,
+    // same quad, k>>1 = 0 / 1) hold (e0,e1) / (e2,e3) and v_permlane32_swap turns that into (e0,e2) / (e1,e3) on arrival — eight
+    // loads per position instead of sixteen (the burst of re-loads, not their bytes, was what the phase waited for)
     const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 64 * 16 * 32);
-    const unsigned lane_x = (unsigned)((k & 1) * 512 + jj * 16 + (k >> 1) * 4);
+    const unsigned lane_x = (unsigned)((k & 1) * 512 + jj * 16 + (k >> 1) * 8);
     f32x2 B[4][8];   // [pw][u] = (slot 2u, slot 2u+1)
-    auto reload = [&](int pw, int pos) {
+    auto reload1 = [&](int pw, int u, int pos) {
         if (ABL & 8) return;
+        B[pw][u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(inb, (int)(lane_x + u * 1024), (int)((unsigned)pos * 8192u), 0));
+    };
+    auto arrive = [&](int pw) {   // the ChannelAttention gate (one packed multiply per pair), then the swap into slot order
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            B[pw][u][0] = buf_ld4(inb, lane_x + u * 1024, (unsigned)pos * 8192u);
-            B[pw][u][1] = buf_ld4(inb, lane_x + u * 1024 + 8, (unsigned)pos * 8192u);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            f32x2 v = B[pw][u];
+            if (!(ABL & 16)) v = v * tg[u];
+            const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+            B[pw][u] = (f32x2){__uint_as_float(r.x), __uint_as_float(r.y)};
         }
     };
     // weights: slice t at t*TR_SLICE; this wave moves bytes [wave*4096, +4096) of every slice
@@ -123,13 +134,18 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
     int t = 0, sl = 0;   // phase (= slice) counter and t % 3
     auto slot_of = [&](int ahead) { const int s = sl + ahead; return s >= TR_RING ? s - TR_RING : s; };
 
-    // ---- prologue: slices 0 and 1, the first row's activations ----
+    // ---- prologue: slices 0 and 1 into the ring, slice 2 into registers, positions 0..2 of the first row ----
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds_w[s * (TR_SLICE / 16) + j * 64] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(s * TR_SLICE + wave * 4096));
+    f32x4 wreg[4];   // this wave's share of the slice two phases ahead: loaded in phase t-1, written to the ring in phase t
 #pragma unroll
-    for (int pw = 0; pw < 4; ++pw) reload(pw, pw);   // unit 0 starts at plane 0, row 0
+    for (int j = 0; j < 4; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(2 * TR_SLICE + wave * 4096));
+#pragma unroll
+    for (int pw = 0; pw < 3; ++pw)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) reload1(pw, u, pw);   // unit 0 starts at plane 0, row 0 (position 3 arrives during phase 0)
     __builtin_amdgcn_s_waitcnt(0x0f70);               // enter the loops with nothing in flight
     __syncthreads();
 
@@ -165,20 +181,16 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
                 auto phase = [&](auto pwc) {
                     constexpr int PW = decltype(pwc)::value;
                     constexpr unsigned NEXT = PW < 3 ? MASK : NMASK;
+                    // the registers of position Q are free during this phase: position 3 of THIS row arrives during phase 0, positions
+                    // 0..2 of the next row during phases 1..3 — requested between the items' MFMA runs, never as one burst (the eight
+                    // waves of a workgroup run in step: 8 x 12 requests at once stall every wave's issue)
+                    constexpr int Q = (PW + 3) & 3;
+                    const int qpos = (PW == 0 ? pcur : pnext) + Q;
                     t = __builtin_amdgcn_readfirstlane(t), sl = __builtin_amdgcn_readfirstlane(sl);   // (loop-carried counters: keep them scalar, the slice offset is the loads' scalar offset)
                     if (!(ABL & 1)) __syncthreads();   // slice t+1 visible to every wave; every wave is done with slice t-1's slot
-                    // this wave's share of slice t+2 (the stream is padded by two slices: no clamp)
-                    f32x4 wreg[4];
-                    if (!(ABL & 2)) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 1024, (unsigned)((t + 2) * TR_SLICE + wave * 4096));
-                    }
-                    // gate the position that arrived a row ago
-                    if (!(ABL & 16)) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) B[PW][u] = B[PW][u] * tg[u];
-                    }
+                    arrive(PW);   // requested three phases ago
                     __builtin_amdgcn_sched_barrier(0);
+                    const int ws = slot_of(2);
                     tr_static_for<NI>([&](auto itc) {
                         constexpr int it = decltype(itc)::value;
                         constexpr int g = it / P, part = it % P, i0 = tr_part_lo(N, part), i1 = tr_part_hi(N, part);
@@ -201,15 +213,17 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
                         // item it+2 of this phase, or item (it+2-NI) of the next one (its slice is in the ring since the last barrier)
                         if constexpr (it + 2 < NI) frag_req(std::integral_constant<unsigned, MASK>{}, std::integral_constant<int, it + 2>{}, sl);
                         else frag_req(std::integral_constant<unsigned, NEXT>{}, std::integral_constant<int, it + 2 - NI>{}, slot_of(1));
+                        // this item's share of the phase's memory traffic: piece k of slice t+2 (in registers since the last phase) goes to
+                        // the ring and its registers take piece k of slice t+3; 8 / NI octets of position Q
+                        if constexpr (it % (NI / 4) == 0 && (ABL & 2) == 0) {
+                            constexpr int kp = it / (NI / 4);
+                            lds_w[ws * (TR_SLICE / 16) + kp * 64] = wreg[kp];
+                            wreg[kp] = buf_ld16(wb, lane_w + kp * 1024, (unsigned)((t + 3) * TR_SLICE + wave * 4096));
+                        }
+#pragma unroll
+                        for (int u = it * (8 / NI); u < (it + 1) * (8 / NI); ++u) reload1(Q, u, qpos);
                         __builtin_amdgcn_sched_barrier(0);
                     });
-                    reload(PW, pnext + PW);   // the same position of the next row
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(ABL & 2)) {
-                        const int ws = slot_of(2);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) lds_w[ws * (TR_SLICE / 16) + j * 64] = wreg[j];
-                    }
                     ++t;
                     sl = slot_of(1);
                 };
