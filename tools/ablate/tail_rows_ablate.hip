@@ -19,6 +19,23 @@ __global__ void fill_k(float* p, size_t n, unsigned seed, float lo, float hi)
 static void fill(float* p, size_t n, unsigned seed, float lo = -1.0f, float hi = 1.0f) { hipLaunchKernelGGL(fill_k, dim3(2048), dim3(256), 0, 0, p, n, seed, lo, hi); }
 
 template <typename K>
+static float run32(const char* name, K k, ConvArgs A)
+{
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL_ROWS);
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    const int g = (A.n_tiles + 3) / 4;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(g), dim3(256), LDS_TAIL_ROWS, 0, A);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k, dim3(g), dim3(256), LDS_TAIL_ROWS, 0, A);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    printf("%-64s %8.4f ms  (%s)\n", name, ms / 10, hipGetErrorString(hipGetLastError()));
+    return ms / 10;
+}
+template <typename K>
 static float run(const char* name, K k, ConvArgs A)
 {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL_ROWS);
@@ -49,7 +66,9 @@ int main()
     ConvArgs A{};
     A.in = in, A.out = out, A.wfrag = w, A.bias_frag = bias, A.se_csum = csum, A.se_fc0 = fc0, A.se_fc2 = fc2, A.n_tiles = nt, A.n_leaves = (int64_t)nt * 32;
 #define T(ABL) run("folded tail (rows16), ABL " #ABL, tail_rows16_k<ABL>, A)
-    // ABL bits: 1 no barriers, 2 no weight streaming, 4 no LDS fragment reads, 8 no activation re-loads, 16 no gate multiply, 32 no epilogue, 128 no MFMAs
-    T(0); T(0); T(1); T(2); T(4); T(8); T(16); T(32); T(63); T(128); T(0);
+    // ABL bits: 1 no barriers, 2 no weight streaming, 4 no LDS fragment reads, 8 no activation re-loads, 16 no gate multiply, 32 no epilogue, 64 no lane swap, 128 no MFMAs
+    T(0); T(0); T(1); T(2); T(4); T(8); T(16); T(80); T(32); T(128); T(0);
+#define U(ABL) run32("folded tail (rows32, 1 wave/SIMD), ABL " #ABL, tail_rows32_k<ABL>, A)
+    U(0); U(0); U(1); U(2); U(4); U(8); U(16); U(80); U(32); U(128); U(0);
     return 0;
 }

@@ -26,7 +26,7 @@ def main():
     rng = np.random.default_rng(5)
     idx = rng.integers(0, 256, size=(a.leaves, 64), dtype=np.uint8)
     outs = {}
-    for variant in ("rows", "slab"):
+    for variant in ("rows", "rows32", "slab"):
         os.environ["VQHIP_TAIL"] = variant
         c = HipCodec(pack)
         c.set_small_batch_tiles(0)
@@ -49,13 +49,18 @@ def main():
         c.profile_enable(False)
         assert np.array_equal(d_out.cpu().numpy().view(np.uint32), rec.view(np.uint32))
         c.close()
-    (sa, ra), (sb, rb) = outs["rows"], outs["slab"]
-    bad = int((ra.view(np.uint32) != rb.view(np.uint32)).sum())
-    print("rows vs slab, full batch: differing words", bad, "of", ra.size)
-    for n in sa:
-        b = int((sa[n].view(np.uint32) != sb[n].view(np.uint32)).sum())
-        print(f"rows vs slab, n={n}: differing words {b}")
+    (sb, rb) = outs["slab"]
+    bad = 0
+    for v in ("rows", "rows32"):
+        (sa, ra) = outs[v]
+        b = int((ra.view(np.uint32) != rb.view(np.uint32)).sum())
+        print(v, "vs slab, full batch: differing words", b, "of", ra.size)
         bad += b
+        for n in sa:
+            b = int((sa[n].view(np.uint32) != sb[n].view(np.uint32)).sum())
+            print(f"{v} vs slab, n={n}: differing words {b}")
+            bad += b
+    ra = outs["rows"][1]
     if not a.skip_oracle:
         from oracle.oracle import Oracle
         o = Oracle(weights, [t[0] for t in synth.TENSORS])

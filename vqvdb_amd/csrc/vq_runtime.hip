@@ -172,6 +172,7 @@ struct vqhip_codec {
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: one kernel; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
     bool stem_taps = true;   // ... the (tap, code) table streamed through an LDS ring tap by tap (stem_taps_k, vq_stem_taps.h: 0.81 -> 0.57 ms); VQHIP_STEM=gather selects stem_fused_k (gather through the L1)
+    bool tail_rows32 = false; // ... VQHIP_TAIL=rows32: a whole 32-leaf tile per wave, one wave per SIMD (tail_rows32_k; measured 3 % slower than two waves per SIMD with a half tile each)
     bool tail_rows = true;   // folded decoder tail of full chunks: 16-voxel tiles, zeros skipped along D and H (tail_rows16_k, vq_tail_rows.h); VQHIP_TAIL=slab selects conv_mfma32_k<OUTMODE 2> (depth only)
     int tail16_tiles = 48;   // small-batch folded tail on the 16x16x4 MFMA up to this many tiles (VQHIP_TAIL16_TILES; measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us)
     bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
@@ -1002,6 +1003,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, conv8_lds_k<true, false, 8, 0, true>, LDS_CONV8))) return rc;
     if ((rc = set_lds(c, k_stem_taps, LDS_STEM_TAPS))) return rc;
     if ((rc = set_lds(c, tail_rows16_k<0>, LDS_TAIL_ROWS))) return rc;
+    if ((rc = set_lds(c, tail_rows32_k<0>, LDS_TAIL_ROWS))) return rc;
     if ((rc = set_lds(c, conv_down_lds_k<0>, LDS_CONVDOWN))) return rc;
     if ((rc = set_lds(c, conv4_lds_k<false, true, false, 0, 1>, LDS_CONV4))) return rc;
     if ((rc = set_lds(c, conv4_lds_k<true, false, true, 0, 0>, LDS_CONV4))) return rc;
@@ -1439,7 +1441,8 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0;
         if (c->tail_rows) {
             A.wfrag = w["tail.wrows"], A.bias_frag = w["tail.braw"];
-            L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_ROWS, s, A); });
+            if (c->tail_rows32) L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows32_k<0>, dim3((nt + 3) / 4), dim3(256), LDS_TAIL_ROWS, s, A); });
+            else L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_ROWS, s, A); });
         } else {
             L.run("dec_tail_slab", [&] { hipLaunchKernelGGL(k_dec_tail, dim3(g8), dim3(512), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
         }
@@ -1779,7 +1782,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_FIRST")) c->first_roll = std::strcmp(e, "steps") != 0, c->first_roll_stats = std::strcmp(e, "roll0") == 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
-    if (const char* e = std::getenv("VQHIP_TAIL")) c->tail_rows = std::strcmp(e, "slab") != 0;
+    if (const char* e = std::getenv("VQHIP_TAIL")) c->tail_rows = std::strcmp(e, "slab") != 0, c->tail_rows32 = std::strcmp(e, "rows32") == 0;
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;

@@ -70,7 +70,7 @@ constexpr int tr_part_lo(int n, int part) { return tr_parts(n) == 1 ? 0 : (part 
 constexpr int tr_part_hi(int n, int part) { return tr_parts(n) == 1 ? n : (part == 0 ? (n + 1) / 2 : n); }
 
 // ABL (tools/ablate/tail_rows_ablate.hip only): 1 no barriers, 2 no weight streaming, 4 no LDS fragment reads, 8 no activation re-loads,
-// 16 no gate multiply, 32 no epilogue, 128 no MFMAs
+// 16 no gate multiply, 32 no epilogue, 64 no lane swap either, 128 no MFMAs
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
 {
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
         for (int u = 0; u < 8; ++u) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             f32x2 v = B[pw][u];
+            if (ABL & 64) continue;
             if (!(ABL & 16)) v = v * tg[u];
             const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
             B[pw][u] = (f32x2){__uint_as_float(r.x), __uint_as_float(r.y)};
@@ -150,6 +151,13 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
     __syncthreads();
 
     f32x4 fa[2][4];   // A-fragment register sets (item j -> set j & 1)
+    if (ABL & 4) {    // (ablation: fragments read once, the MFMAs keep real operands)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[i >> 2][i & 3] = lds_r[i * 64];
+            asm volatile("" : "+v"(fa[i >> 2][i & 3]));
+        }
+    }
     // fragments of item `it` of a phase with active mask M, from ring slot `slot`
     auto frag_req = [&](auto mc, auto itc, int slot) {
         constexpr unsigned M = decltype(mc)::value;
@@ -270,6 +278,217 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
         const int od0 = unit == 0 ? 0 : unit == 4 ? 7 : 2 * unit - 1;
         const int pd_lo = unit <= 2 ? 0 : unit - 2, pd_hi = unit >= 2 ? 3 : unit + 1;
         const int nlo = unit + 1 <= 2 ? 0 : unit - 1;   // first plane of unit + 1
+        const int p_next_unit = unit < 4 ? nlo * 16 : 60;
+        if (unit == 0 || unit == 4) run_unit(std::false_type{}, od0, pd_lo, pd_hi, p_next_unit);
+        else run_unit(std::true_type{}, od0, pd_lo, pd_hi, p_next_unit);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same operator with a whole 32-leaf tile per wave and ONE wave per SIMD (512 registers): every weight fragment read from LDS
+// feeds two MFMAs (the tile's two 16-leaf halves), so the LDS reads, the fragment waits and the lock-step of two waves sharing a
+// matrix pipe are halved; nothing but this wave's own instruction stream sits between its MFMAs, and that stream is static.
+// A workgroup = 4 waves = 128 leaves behind one weight stream (as above).  Activations: the tile's natural float4 (lane = (leaf,
+// quad), fully coalesced 1 KB per load, eight per position); v_permlane32_swap of (x,y) and (z,w) turns a float4 into the four
+// operands (half 0 mf 0, half 1 mf 0, half 0 mf 1, half 1 mf 1) after the gate multiply.
+// ------------------------------------------------------------------------------------------
+constexpr int TR32_WAVES = 4;
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 1) void tail_rows32_k(ConvArgs A)
+{
+    static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, k = lane >> 4;
+    int tile = blockIdx.x * TR32_WAVES + wave;
+    const bool active = tile < A.n_tiles;
+    if (!active) tile = A.n_tiles - 1;   // a wave without a tile re-computes the last one (it carries its share of the weights)
+    // load lane = (leaf jl of the tile, quad ql): lanes 0-31 hold half 0, lanes 32-63 half 1
+    const int jl = 16 * (lane >> 5) + n, ql = k & 1;
+
+    // ---- ChannelAttention gates of the four channels 8u + 4 ql + {0..3} of leaf jl, applied before the lane swap ----
+    f32x4 tg[8];
+    {
+        float hid[16], gall[64];
+        se_hidden<64>(A.se_csum + (size_t)tile * 64 * 32 + jl, A.se_fc0, hid);
+        se_gates<64>(hid, A.se_fc2, gall);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tg[u][e] = ql ? gall[8 * u + 4 + e] : gall[8 * u + e];
+    }
+    const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 64 * 16 * 32);
+    const unsigned lane_x = (unsigned)(ql * 512 + jl * 16);
+    // Two register sets: Bc = the position the MFMAs of this phase read (gated, swapped), Bn = the next position in flight (raw):
+    // requested in the first half of a phase, it has the other half to arrive (an HBM round trip is a tenth of a phase)
+    f32x4 Bc[8], Bn[8];   // Bc[u] = (half 0 slot 2u, half 1 slot 2u, half 0 slot 2u+1, half 1 slot 2u+1)
+    auto reload1 = [&](int u, int pos) {
+        if (ABL & 8) return;
+        Bn[u] = buf_ld16(inb, lane_x + u * 1024, (unsigned)pos * 8192u);
+    };
+    auto arrive = [&]() {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            f32x4 v = Bn[u];
+            if (ABL & 64) { Bc[u] = v; continue; }
+            if (!(ABL & 16)) v = v * tg[u];
+            const u32x2 r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+            const u32x2 r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+            Bc[u] = (f32x4){__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y)};
+        }
+    };
+    // weights: slice t at t*TR_SLICE; this wave moves bytes [wave*8192, +8192) of every slice
+    const vq_buf wb = buf_of(A.wfrag);
+    const unsigned lane_w = (unsigned)lane * 16u;
+    f32x4* const lds_w = (f32x4*)(smem_raw + wave * 8192) + lane;   // + slot*TR_SLICE/16 + j*64
+    const f32x4* const lds_r = (const f32x4*)smem_raw + lane;       // + slot*TR_SLICE/16 + (tile i*4 + g)*64
+    const vq_buf outb = buf_of(A.out + (size_t)tile * 32 * 512);
+    const float* bias = A.bias_frag;
+
+    int t = 0, sl = 0;
+    auto slot_of = [&](int ahead) { const int s = sl + ahead; return s >= TR_RING ? s - TR_RING : s; };
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_w[s * (TR_SLICE / 16) + j * 64] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(s * TR_SLICE + wave * 8192));
+    f32x4 wreg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(2 * TR_SLICE + wave * 8192));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) reload1(u, 0);   // unit 0 starts at plane 0, row 0, position 0
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    f32x4 fa[2][4];
+    if (ABL & 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[i >> 2][i & 3] = lds_r[i * 64];
+            asm volatile("" : "+v"(fa[i >> 2][i & 3]));
+        }
+    }
+    auto frag_req = [&](auto mc, auto itc, int slot) {
+        constexpr unsigned M = decltype(mc)::value;
+        constexpr int it = decltype(itc)::value;
+        constexpr int N = tr_popc(M), P = tr_parts(N), g = it / P, part = it % P;
+        if (ABL & 4) return;
+#pragma unroll
+        for (int i = tr_part_lo(N, part); i < tr_part_hi(N, part); ++i) fa[it & 1][i - tr_part_lo(N, part)] = lds_r[slot * (TR_SLICE / 16) + (i * 4 + g) * 64];
+    };
+
+    auto run_unit = [&](auto pair_c, const int od0, const int pd_lo, const int pd_hi, const int p_next_unit) {
+        constexpr bool PAIR = decltype(pair_c)::value;
+        constexpr int NT = PAIR ? 8 : 4;
+        f32x4 tot[2][NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) tot[0][i] = tot[1][i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        frag_req(std::integral_constant<unsigned, tr_mask(PAIR, 0)>{}, std::integral_constant<int, 0>{}, sl);
+        frag_req(std::integral_constant<unsigned, tr_mask(PAIR, 0)>{}, std::integral_constant<int, 1>{}, sl);
+#pragma nounroll
+        for (int pd = pd_lo; pd <= pd_hi; ++pd) {
+            auto row = [&](auto phc) {
+                constexpr int PH = decltype(phc)::value;
+                constexpr unsigned MASK = tr_mask(PAIR, PH), NMASK = tr_mask(PAIR, (PH + 1) & 3);
+                constexpr int N = tr_popc(MASK), P = tr_parts(N), NI = 4 * P;
+                const int pcur = (pd * 4 + PH) * 4;
+                const int pnext = (PH == 3 && pd == pd_hi) ? p_next_unit : pcur + 4;
+                f32x4 acc[2][NT];
+                auto phase = [&](auto pwc) {
+                    constexpr int PW = decltype(pwc)::value;
+                    constexpr unsigned NEXT = PW < 3 ? MASK : NMASK;
+                    const int qpos = PW < 3 ? pcur + PW + 1 : pnext;   // the position the next phase reads
+                    t = __builtin_amdgcn_readfirstlane(t), sl = __builtin_amdgcn_readfirstlane(sl);
+                    if (!(ABL & 1)) __syncthreads();
+                    arrive();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ws = slot_of(2);
+                    tr_static_for<NI>([&](auto itc) {
+                        constexpr int it = decltype(itc)::value;
+                        constexpr int g = it / P, part = it % P, i0 = tr_part_lo(N, part), i1 = tr_part_hi(N, part);
+                        tr_static_for<4>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value, s = 4 * g + e;
+                            tr_static_for<i1 - i0>([&](auto ic) {
+                                constexpr int i = i0 + decltype(ic)::value, tid = tr_nth(MASK, i);
+                                const float a = fa[it & 1][i - i0][e];
+                                tr_static_for<2>([&](auto hc) {
+                                    constexpr int h = decltype(hc)::value;
+                                    const float b = Bc[s >> 1][2 * (s & 1) + h];
+                                    if constexpr ((ABL & 128) != 0) {
+                                        if constexpr (PW == 0 && s == 0) acc[h][tid][0] = a * b;
+                                        else acc[h][tid][0] += a * b;
+                                    } else if constexpr (PW == 0 && s == 0) {
+                                        acc[h][tid] = mfma16(a, b, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+                                    } else {
+                                        acc[h][tid] = mfma16(a, b, acc[h][tid]);
+                                    }
+                                });
+                            });
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (it + 2 < NI) frag_req(std::integral_constant<unsigned, MASK>{}, std::integral_constant<int, it + 2>{}, sl);
+                        else frag_req(std::integral_constant<unsigned, NEXT>{}, std::integral_constant<int, it + 2 - NI>{}, slot_of(1));
+                        if constexpr ((ABL & 2) == 0) {
+#pragma unroll
+                            for (int kp = it * (8 / NI); kp < (it + 1) * (8 / NI); ++kp) {
+                                lds_w[ws * (TR_SLICE / 16) + kp * 64] = wreg[kp];
+                                wreg[kp] = buf_ld16(wb, lane_w + kp * 1024, (unsigned)((t + 3) * TR_SLICE + wave * 8192));
+                            }
+                        }
+                        // the next position: all of it in the first half of the phase
+                        if constexpr (it < NI / 2) {
+#pragma unroll
+                            for (int u = it * (16 / NI); u < (it + 1) * (16 / NI); ++u) reload1(u, qpos);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    ++t;
+                    sl = slot_of(1);
+                };
+                phase(std::integral_constant<int, 0>{});
+                phase(std::integral_constant<int, 1>{});
+                phase(std::integral_constant<int, 2>{});
+                phase(std::integral_constant<int, 3>{});
+                tr_static_for<N>([&](auto ic) {
+                    constexpr int tid = tr_nth(MASK, decltype(ic)::value);
+                    tot[0][tid] = tot[0][tid] + acc[0][tid];
+                    tot[1][tid] = tot[1][tid] + acc[1][tid];
+                });
+            };
+            row(std::integral_constant<int, 0>{});
+            row(std::integral_constant<int, 1>{});
+            row(std::integral_constant<int, 2>{});
+            row(std::integral_constant<int, 3>{});
+        }
+        if (ABL & 32) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) s += tot[0][i][0] + tot[0][i][3] + tot[1][i][0] + tot[1][i][3];
+            if (s == 12345.678f) A.out[threadIdx.x] = s;
+            return;
+        }
+#pragma unroll
+        for (int tid = 0; tid < NT; ++tid) {
+            const int ca = PAIR ? od0 * 8 + tid : od0 * 8 + (tid == 3 ? 0 : 2 * tid + 1);
+            const int cb = PAIR ? (od0 + 1) * 8 + tid : od0 * 8 + (tid == 3 ? 7 : 2 * tid + 2);
+            const int vox = (k < 2 ? ca : cb) * 8 + (k & 1) * 4;
+            const f32x4 bv = *(const f32x4*)(bias + vox);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 sg;
+                sg.x = vq_sigmoid(tot[h][tid].x + bv.x), sg.y = vq_sigmoid(tot[h][tid].y + bv.y);
+                sg.z = vq_sigmoid(tot[h][tid].z + bv.z), sg.w = vq_sigmoid(tot[h][tid].w + bv.w);
+                const int jj = 16 * h + n;
+                if (active && (int64_t)tile * 32 + jj < A.n_leaves) buf_st16(sg, outb, (unsigned)(jj * 512 + vox) * 4u, 0u);
+            }
+        }
+    };
+#pragma nounroll
+    for (int unit = 0; unit < 5; ++unit) {
+        const int od0 = unit == 0 ? 0 : unit == 4 ? 7 : 2 * unit - 1;
+        const int pd_lo = unit <= 2 ? 0 : unit - 2, pd_hi = unit >= 2 ? 3 : unit + 1;
+        const int nlo = unit + 1 <= 2 ? 0 : unit - 1;
         const int p_next_unit = unit < 4 ? nlo * 16 : 60;
         if (unit == 0 || unit == 4) run_unit(std::false_type{}, od0, pd_lo, pd_hi, p_next_unit);
         else run_unit(std::true_type{}, od0, pd_lo, pd_hi, p_next_unit);
