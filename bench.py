@@ -153,6 +153,23 @@ def path_traffic(kernels):
     return tot
 
 
+# FLOPs per leaf a kernel issues that the RESULT does not need (they are inside issued_flop_per_leaf): the first conv is run twice
+# (statistics pass, then recompute + normalise + store: the first pass's MACs buy no output), and the folded decoder tail multiplies the
+# structural zeros its 16-voxel tiles cannot skip (884 736 MAC/leaf are structurally non-zero; the corner tiles and the W axis are issued in full)
+NOT_USEFUL_FLOP = {"enc_conv_first_stats": None, "dec_tail": lambda issued: issued - 2.0 * 884736, "dec_tail_slab": lambda issued: issued - 2.0 * 884736}
+
+
+def useful_flop_per_leaf(kernels):
+    tot = 0.0
+    for k in kernels:
+        f = k["issued_flop_per_leaf"]
+        if k["kernel"] in NOT_USEFUL_FLOP:
+            g = NOT_USEFUL_FLOP[k["kernel"]]
+            f = 0.0 if g is None else f - g(f)
+        tot += f
+    return tot
+
+
 def roofline_of(kernels, nominal_flop_per_leaf, leaves_per_s_per_gpu):
     """Roofline of the dominant kernel (longest average launch).  `achieved`/`frac` count the FLOPs the kernel ISSUES on the
     matrix pipe (zero-padding taps are skipped, folded operators counted at their folded cost) — a true utilisation, <= 1, that
@@ -176,6 +193,9 @@ def roofline_of(kernels, nominal_flop_per_leaf, leaves_per_s_per_gpu):
         "achieved_nominal_dense": dom["tflops_nominal_dense"], "ratio_nominal_dense_to_peak": round(dom["tflops_nominal_dense"] / PEAK_TF, 4),
         "whole_path_frac": round(leaves_per_s_per_gpu * issued_per_leaf / (PEAK_TF * 1e12), 4),
         "whole_path_issued_flop_per_leaf": issued_per_leaf,
+        # ... counting only the FLOPs the result needs (no structural-zero MACs of the folded tail, the first conv once)
+        "whole_path_frac_useful": round(leaves_per_s_per_gpu * useful_flop_per_leaf(kernels) / (PEAK_TF * 1e12), 4),
+        "whole_path_useful_flop_per_leaf": useful_flop_per_leaf(kernels),
         "whole_path_ratio_nominal_dense_to_peak": round(leaves_per_s_per_gpu * nominal_flop_per_leaf / (PEAK_TF * 1e12), 4),
         "note": "achieved = FLOPs issued on the matrix pipe per launch / average launch time (HIP events on the launch stream); frac = achieved / peak; "
                 "whole_path_frac = leaves/s x issued FLOP per leaf of every kernel of the pass / peak; *_nominal_dense = dense FLOP count of the reference ops "
@@ -492,6 +512,8 @@ def main():
             host = host_legs(args)
         elif world > 1:
             host = {"skipped": "host-memory legs run at N = 1 only (one process per GPU already saturates its PCIe link)"}
+        enc_roof, dec_roof = roofline_of(ek, ENC_FLOP, enc_lps / world), roofline_of(dk, DEC_FLOP, dec_lps / world)
+        dtail = next((k for k in dk if k["kernel"].startswith("dec_tail")), None)
         out = {
             "metric": "8^3 leaves/s encode+quantize (decode reported under 'decode')",
             "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -502,17 +524,27 @@ def main():
                                     f"(>= the 8 Mi-leaf shard of the 64M-leaf job; 65536-leaf batches), fp32 encoder+quantizer, K=256 D=128"),
                        "leaves_per_step_per_gpu": BATCH, "leaves_per_gpu": steps * BATCH, "steps_requested": args.steps,
                        "sharding": f"leaves sharded over {world} rank(s), no data-path collective"},
+            # flat copies of the figures a summariser that drops nested objects would lose (the nested objects below stay authoritative)
+            "decode_value": round(dec_lps, 1), "decode_ms_per_step": round(t_dec / steps * 1e3, 4),
+            "roofline_frac": enc_roof["frac"], "decode_roofline_frac": dec_roof["frac"],
+            "whole_path_frac": enc_roof["whole_path_frac"], "decode_whole_path_frac": dec_roof["whole_path_frac"],
+            "whole_path_frac_useful": enc_roof["whole_path_frac_useful"], "decode_whole_path_frac_useful": dec_roof["whole_path_frac_useful"],
+            "dec_tail_ms": dtail["avg_ms"] if dtail else None, "dec_tail_issued_flop_per_leaf": dtail["issued_flop_per_leaf"] if dtail else None,
+            "traffic_stale": enc_roof["traffic_stale"], "decode_traffic_stale": dec_roof["traffic_stale"],
+            "n_devices_seen": len(devices_seen),
+            "per_rank_encode_min": per_rank["encode_min_max"][0] if per_rank else None, "per_rank_encode_max": per_rank["encode_min_max"][1] if per_rank else None,
+            "per_rank_decode_min": per_rank["decode_min_max"][0] if per_rank else None, "per_rank_decode_max": per_rank["decode_min_max"][1] if per_rank else None,
             "collective_backend": ("nccl (RCCL)" if backend == "nccl" else backend) if dist else None,
             "ranks_seen": ranks_seen,
             "devices_seen": devices_seen,
             "per_rank": per_rank,
             "cpu_affinity": affinity,
-            "roofline": roofline_of(ek, ENC_FLOP, enc_lps / world),
+            "roofline": enc_roof,
             "cpu_baseline": cpu,
             "decode": {
                 "value": round(dec_lps, 1), "unit": "leaves/s", "ms_per_step": round(t_dec / steps * 1e3, 4), "timed_region_s": round(t_dec, 4),
                 "workload": "decode of 65536-leaf index batches resident in HBM (kernel path of BASELINE configs[2]; the file-level run is under 'config3')",
-                "roofline": roofline_of(dk, DEC_FLOP, dec_lps / world),
+                "roofline": dec_roof,
             },
             "kernels": {"encode": ek, "decode": dk},
             "flop_per_leaf": {"encode_nominal_dense": ENC_FLOP, "decode_nominal_dense": DEC_FLOP,

@@ -489,13 +489,14 @@ def test_large_path_kernel_variants_agree(pack, oracle, monkeypatch):
     16-channel convs instead of the 16-wave one; VQHIP_STEM=split: gather and GroupNorm as two kernels; VQHIP_STEM=gather: the fused decoder front gathering the (tap, code)
     table through the L1 (stem_fused_k) instead of streaming it through an LDS ring tap by tap (stem_taps_k, the default); VQHIP_CONV4=rows /
     VQHIP_DOWN=rows: the encoder's 4^3 convs on the row kernel — weights in LDS, input rows re-loaded — instead of the LDS plane rings
-    conv4_lds_k / conv_down_lds_k).  All of them implement the same arithmetic contract: identical indices, voxels and (debug mode)
+    conv4_lds_k / conv_down_lds_k; VQHIP_TAIL = slab | groups | rows32: the folded decoder tail skipping structural zeros along depth only
+    (conv_mfma32_k), in three plane groups, or with a whole tile per wave, instead of tail_rows16_k).  All of them implement the same arithmetic contract: identical indices, voxels and (debug mode)
     encoder intermediates, and the oracle's on a sample."""
     leaves = np.concatenate([synth.make_leaves(2200, seed=31), synth.sparse_leaves(300, seed=32), synth.edge_leaves()])
     ref_idx = ref_rec = None
     for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}, {"VQHIP_STEM": "gather"}, {"VQHIP_FIRST": "steps"}, {"VQHIP_FIRST": "roll0"}, {"VQHIP_CONV4": "rows"},
-                {"VQHIP_DOWN": "rows"}, {"VQHIP_CONV4": "rows", "VQHIP_DOWN": "rows"}):
-        for k in ("VQHIP_CONV8", "VQHIP_STEM", "VQHIP_CONV4", "VQHIP_DOWN"):
+                {"VQHIP_DOWN": "rows"}, {"VQHIP_CONV4": "rows", "VQHIP_DOWN": "rows"}, {"VQHIP_TAIL": "slab"}, {"VQHIP_TAIL": "groups"}, {"VQHIP_TAIL": "rows32"}):
+        for k in ("VQHIP_CONV8", "VQHIP_STEM", "VQHIP_CONV4", "VQHIP_DOWN", "VQHIP_FIRST", "VQHIP_TAIL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -26,7 +26,7 @@ def main():
     rng = np.random.default_rng(5)
     idx = rng.integers(0, 256, size=(a.leaves, 64), dtype=np.uint8)
     outs = {}
-    for variant in ("rows", "rows32", "slab"):
+    for variant in ("rows16", "groups", "rows32", "slab"):
         os.environ["VQHIP_TAIL"] = variant
         c = HipCodec(pack)
         c.set_small_batch_tiles(0)
@@ -51,7 +51,7 @@ def main():
         c.close()
     (sb, rb) = outs["slab"]
     bad = 0
-    for v in ("rows", "rows32"):
+    for v in ("groups", "rows16", "rows32"):
         (sa, ra) = outs[v]
         b = int((ra.view(np.uint32) != rb.view(np.uint32)).sum())
         print(v, "vs slab, full batch: differing words", b, "of", ra.size)
@@ -60,7 +60,7 @@ def main():
             b = int((sa[n].view(np.uint32) != sb[n].view(np.uint32)).sum())
             print(f"{v} vs slab, n={n}: differing words {b}")
             bad += b
-    ra = outs["rows"][1]
+    ra = outs["rows16"][1]
     if not a.skip_oracle:
         from oracle.oracle import Oracle
         o = Oracle(weights, [t[0] for t in synth.TENSORS])

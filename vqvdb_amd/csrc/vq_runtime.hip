@@ -35,6 +35,7 @@
 #include "vq_grad_kernels.h"
 #include "vq_train_tail.h"
 #include "vq_tail_rows.h"
+#include "vq_tail_groups.h"
 
 namespace {
 
@@ -172,7 +173,8 @@ struct vqhip_codec {
     int n_cus = 256;         // compute units of the device (persistent-workgroup launches)
     bool stem_fused = true;  // decoder front of large passes: one kernel; VQHIP_STEM=split selects stem_lut_k + gn_relu_stats_k
     bool stem_taps = true;   // ... the (tap, code) table streamed through an LDS ring tap by tap (stem_taps_k, vq_stem_taps.h: 0.81 -> 0.57 ms); VQHIP_STEM=gather selects stem_fused_k (gather through the L1)
-    bool tail_rows32 = false; // ... VQHIP_TAIL=rows32: a whole 32-leaf tile per wave, one wave per SIMD (tail_rows32_k; measured 3 % slower than two waves per SIMD with a half tile each)
+    bool tail_groups = false; // ... VQHIP_TAIL=groups: the output planes in three groups instead of five units, every input plane read 2.5x instead of 3.5x (tail_groups16_k, vq_tail_groups.h; measured equal in time, 33 spilled registers)
+    bool tail_rows32 = false; // ... VQHIP_TAIL=rows32: a whole 32-leaf tile per wave, one wave per SIMD (tail_rows32_k; measured 4 % slower)
     bool tail_rows = true;   // folded decoder tail of full chunks: 16-voxel tiles, zeros skipped along D and H (tail_rows16_k, vq_tail_rows.h); VQHIP_TAIL=slab selects conv_mfma32_k<OUTMODE 2> (depth only)
     int tail16_tiles = 48;   // small-batch folded tail on the 16x16x4 MFMA up to this many tiles (VQHIP_TAIL16_TILES; measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us)
     bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
@@ -674,7 +676,36 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
         }
         if (t != TR_PHASES || tile_rows != TR_TILE_ROWS) return fail(c, VQHIP_ERR_MODEL, "folded tail: row schedule does not match tail_rows16_k");
     }
+    // ... and of tail_groups16_k (vq_tail_groups.h): three groups of output planes, 48 KB slices of up to 11 blocks (pair tiles, then the
+    // group's single tiles while their planes last)
+    std::vector<float> wgroups((size_t)TG_STREAM_SLICES * (TG_SLICE / 4), 0.0f);
+    {
+        size_t t = 0, tile_rows = 0;
+        for (int g = 0; g < 3; ++g)
+            for (int pd = tg_pd_lo(g); pd <= tg_pd_hi(g); ++pd)
+                for (int ph = 0; ph < 4; ++ph) {
+                    const unsigned mask = tg_mask(tg_with_single(g, pd), ph);
+                    tile_rows += tr_popc(mask);
+                    for (int pw = 0; pw < 4; ++pw, ++t) {
+                        const int p = (pd * 4 + ph) * 4 + pw;
+                        for (int i = 0; i < tr_popc(mask); ++i) {
+                            const int tid = tr_nth(mask, i), ca = tg_cell_a(g, tid), cb = tg_cell_b(g, tid);
+                            float* blk = &wgroups[t * (TG_SLICE / 4) + (size_t)i * 1024];
+                            for (int uu = 0; uu < 4; ++uu)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int u = 2 * uu + (e >> 1), mf = e & 1, m = lane & 15, k = lane >> 4;
+                                        const int ch = 8 * u + 4 * (k & 1) + (k >> 1) + 2 * mf;
+                                        const int vox = (m < 8 ? ca : cb) * 8 + (m & 7);
+                                        blk[(uu * 64 + lane) * 4 + e] = wc[((size_t)vox * 64 + p) * 64 + ch];
+                                    }
+                        }
+                    }
+                }
+        if (t != TG_PHASES || tile_rows != TR_TILE_ROWS) return fail(c, VQHIP_ERR_MODEL, "folded tail: group schedule does not match tail_groups16_k");
+    }
     int rc;
+    if ((rc = upload(c, "tail.wgroups", wgroups))) return rc;
     if ((rc = upload(c, "tail.wrows", wrows))) return rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
@@ -1004,6 +1035,7 @@ int init_kernel_attrs(vqhip_codec* c)
     if ((rc = set_lds(c, k_stem_taps, LDS_STEM_TAPS))) return rc;
     if ((rc = set_lds(c, tail_rows16_k<0>, LDS_TAIL_ROWS))) return rc;
     if ((rc = set_lds(c, tail_rows32_k<0>, LDS_TAIL_ROWS))) return rc;
+    if ((rc = set_lds(c, tail_groups16_k<0>, LDS_TAIL_GROUPS))) return rc;
     if ((rc = set_lds(c, conv_down_lds_k<0>, LDS_CONVDOWN))) return rc;
     if ((rc = set_lds(c, conv4_lds_k<false, true, false, 0, 1>, LDS_CONV4))) return rc;
     if ((rc = set_lds(c, conv4_lds_k<true, false, true, 0, 0>, LDS_CONV4))) return rc;
@@ -1441,7 +1473,10 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
         A.n_steps = c->nsteps["steps.tail"], A.n_taps = 0;
         if (c->tail_rows) {
             A.wfrag = w["tail.wrows"], A.bias_frag = w["tail.braw"];
-            if (c->tail_rows32) L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows32_k<0>, dim3((nt + 3) / 4), dim3(256), LDS_TAIL_ROWS, s, A); });
+            if (c->tail_groups) {
+                A.wfrag = w["tail.wgroups"];
+                L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_groups16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_GROUPS, s, A); });
+            } else if (c->tail_rows32) L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows32_k<0>, dim3((nt + 3) / 4), dim3(256), LDS_TAIL_ROWS, s, A); });
             else L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_ROWS, s, A); });
         } else {
             L.run("dec_tail_slab", [&] { hipLaunchKernelGGL(k_dec_tail, dim3(g8), dim3(512), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
@@ -1782,7 +1817,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_FIRST")) c->first_roll = std::strcmp(e, "steps") != 0, c->first_roll_stats = std::strcmp(e, "roll0") == 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
-    if (const char* e = std::getenv("VQHIP_TAIL")) c->tail_rows = std::strcmp(e, "slab") != 0, c->tail_rows32 = std::strcmp(e, "rows32") == 0;
+    if (const char* e = std::getenv("VQHIP_TAIL")) c->tail_rows = std::strcmp(e, "slab") != 0, c->tail_rows32 = std::strcmp(e, "rows32") == 0, c->tail_groups = std::strcmp(e, "groups") == 0;
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;

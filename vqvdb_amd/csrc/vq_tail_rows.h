@@ -22,9 +22,9 @@
 // Five units of output planes, od = {0}, {1,2}, {3,4}, {5,6}, {7}; a unit walks the input rows (pd in its reach, ph = 0..3) once:
 //   row = 4 phases (pw = 0..3); phase = the active tiles' 16 MFMAs each (K = 64 channels of one input position), tiles interleaved
 //   (3-4 accumulators in rotation), fragments of item j+2 requested from LDS when item j has issued (two register sets).
-//   The activations of a row sit in 64 registers (one dword per MFMA slot: the P8 order needs channel pairs (c, c+2), so dword
-//   loads, not the float4 the 32x32x2 kernel shares between two K slots), gated on arrival (ChannelAttention, v_pk_mul), re-loaded
-//   for the next row right after the phase that used them last.
+//   The activations of ONE position sit in 16 registers (one per MFMA slot), the next position's in 16 more: requested in the first
+//   half of a phase as four dwordx4 (a lane loads a channel quad of its leaf; the P8 order wants element pairs (e, e+2) of it: lanes L
+//   and L+32 exchange halves with v_permlane32_swap), gated (ChannelAttention, v_pk_mul) and swapped at the start of the next phase.
 //   Weights: one 32 KB slice per phase (dense list of the active tiles' 4 KB blocks; laid out by the host in consumption order),
 //   global -> register (one phase) -> LDS into a ring of three slices, written two phases ahead; ONE barrier per phase publishes
 //   slice t+1 and frees the slot of slice t-1, so the first fragments of the next phase are read BEFORE its barrier.
@@ -85,43 +85,49 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
     const int tile = half >> 1, jj = 16 * (half & 1) + n;
     const bool store = active && (int64_t)tile * 32 + jj < A.n_leaves;
 
-    // ---- ChannelAttention gates of this lane's 16 channels.  MFMA slot s = 2u + mf holds channel 8u + 4(k&1) + (k>>1) + 2mf; the
-    // gates are applied BEFORE the lane swap below, i.e. to the channel pair (8u + 4(k&1) + 2(k>>1), +1) the lane loads ----
-    f32x2 tg[8];
+    // Activations: element (pos, channel c, leaf) at pos*8192 + (c>>2)*512 + leaf*16 + (c&3)*4 bytes of the tile.  Lane (n, k) loads
+    // the whole channel quad 4j + k of its leaf (j = 0..3: four dwordx4 per position, 1 KB each — every vector-memory instruction
+    // issued into the MFMA stream costs the wave ~100 cycles, their number is what counts); MFMA slot s = 2u + mf of lane (n, k) wants
+    // channel 8u + 4(k&1) + (k>>1) + 2mf: for octet u = 2j the lanes k = 0,1 hold the right quad and want its elements (0,2), the
+    // lanes k = 2,3 want elements (1,3) of the quad their partner lane L-32 holds; for octet 2j+1 it is the other way round, so
+    // v_permlane32_swap of (x,y) and of (z,w) turns one float4 into (octet 2j mf 0, octet 2j+1 mf 0, octet 2j mf 1, octet 2j+1 mf 1).
+    // ChannelAttention gates are applied BEFORE the swap, to the quad the lane loaded.
+    f32x4 tg[4];
     {
         float hid[16], gall[64];
         se_hidden<64>(A.se_csum + (size_t)tile * 64 * 32 + jj, A.se_fc0, hid);
         se_gates<64>(hid, A.se_fc2, gall);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c0 = 8 * u + e;
-                const float lo = (k >> 1) ? gall[c0 + 2] : gall[c0], hi = (k >> 1) ? gall[c0 + 6] : gall[c0 + 4];
-                tg[u][e] = (k & 1) ? hi : lo;
+            for (int e = 0; e < 4; ++e) {
+                // (bit selects: written as ?: the compiler turns the four-way choice into an indexed read of gall[] from scratch)
+                const int c0 = 16 * j + e;
+                const unsigned m1 = 0u - (unsigned)(k & 1), m2 = 0u - (unsigned)(k >> 1);
+                const unsigned lo = (__float_as_uint(gall[c0 + 4]) & m1) | (__float_as_uint(gall[c0]) & ~m1);
+                const unsigned hi = (__float_as_uint(gall[c0 + 12]) & m1) | (__float_as_uint(gall[c0 + 8]) & ~m1);
+                tg[j][e] = __uint_as_float((hi & m2) | (lo & ~m2));
             }
     }
-
-    // activations: element (pos, channel c, leaf jj) at pos*8192 + (c>>2)*512 + jj*16 + (c&3)*4 bytes of the tile.  A lane loads the
-    // channel PAIR (4(k&1) + 2(k>>1), +1) of octet u as one dwordx2; it needs (4(k&1) + (k>>1), +2): lanes L and L+32 (same leaf,
-    // same quad, k>>1 = 0 / 1) hold (e0,e1) / (e2,e3) and v_permlane32_swap turns that into (e0,e2) / (e1,e3) on arrival — eight
-    // loads per position instead of sixteen (the burst of re-loads, not their bytes, was what the phase waited for)
     const vq_buf inb = buf_of((const f32x4*)A.in + (size_t)tile * 64 * 16 * 32);
-    const unsigned lane_x = (unsigned)((k & 1) * 512 + jj * 16 + (k >> 1) * 8);
-    f32x2 B[4][8];   // [pw][u] = (slot 2u, slot 2u+1)
-    auto reload1 = [&](int pw, int u, int pos) {
+    const unsigned lane_x = (unsigned)(k * 512 + jj * 16);
+    // Bc = the position this phase's MFMAs read (gated, swapped: Bc[j] = (slot 4j, slot 4j+2, slot 4j+1, slot 4j+3)), Bn = the next
+    // position, raw, requested in the first half of the phase
+    f32x4 Bc[4], Bn[4];
+    auto reload1 = [&](int j, int pos) {
         if (ABL & 8) return;
-        B[pw][u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(inb, (int)(lane_x + u * 1024), (int)((unsigned)pos * 8192u), 0));
+        Bn[j] = buf_ld16(inb, lane_x + j * 2048, (unsigned)pos * 8192u);
     };
-    auto arrive = [&](int pw) {   // the ChannelAttention gate (one packed multiply per pair), then the swap into slot order
+    auto arrive = [&]() {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int j = 0; j < 4; ++j) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            f32x2 v = B[pw][u];
-            if (ABL & 64) continue;
-            if (!(ABL & 16)) v = v * tg[u];
-            const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
-            B[pw][u] = (f32x2){__uint_as_float(r.x), __uint_as_float(r.y)};
+            f32x4 v = Bn[j];
+            if (ABL & 64) { Bc[j] = v; continue; }
+            if (!(ABL & 16)) v = v * tg[j];
+            const u32x2 r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+            const u32x2 r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+            Bc[j] = (f32x4){__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y)};
         }
     };
     // weights: slice t at t*TR_SLICE; this wave moves bytes [wave*4096, +4096) of every slice
@@ -144,9 +150,7 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
 #pragma unroll
     for (int j = 0; j < 4; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(2 * TR_SLICE + wave * 4096));
 #pragma unroll
-    for (int pw = 0; pw < 3; ++pw)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) reload1(pw, u, pw);   // unit 0 starts at plane 0, row 0 (position 3 arrives during phase 0)
+    for (int j = 0; j < 4; ++j) reload1(j, 0);   // unit 0 starts at plane 0, row 0, position 0
     __builtin_amdgcn_s_waitcnt(0x0f70);               // enter the loops with nothing in flight
     __syncthreads();
 
@@ -189,14 +193,10 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
                 auto phase = [&](auto pwc) {
                     constexpr int PW = decltype(pwc)::value;
                     constexpr unsigned NEXT = PW < 3 ? MASK : NMASK;
-                    // the registers of position Q are free during this phase: position 3 of THIS row arrives during phase 0, positions
-                    // 0..2 of the next row during phases 1..3 — requested between the items' MFMA runs, never as one burst (the eight
-                    // waves of a workgroup run in step: 8 x 12 requests at once stall every wave's issue)
-                    constexpr int Q = (PW + 3) & 3;
-                    const int qpos = (PW == 0 ? pcur : pnext) + Q;
+                    const int qpos = PW < 3 ? pcur + PW + 1 : pnext;   // the position the next phase reads
                     t = __builtin_amdgcn_readfirstlane(t), sl = __builtin_amdgcn_readfirstlane(sl);   // (loop-carried counters: keep them scalar, the slice offset is the loads' scalar offset)
                     if (!(ABL & 1)) __syncthreads();   // slice t+1 visible to every wave; every wave is done with slice t-1's slot
-                    arrive(PW);   // requested three phases ago
+                    arrive();
                     __builtin_amdgcn_sched_barrier(0);
                     const int ws = slot_of(2);
                     tr_static_for<NI>([&](auto itc) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
                             constexpr int e = decltype(ec)::value, s = 4 * g + e;
                             tr_static_for<i1 - i0>([&](auto ic) {
                                 constexpr int i = i0 + decltype(ic)::value, tid = tr_nth(MASK, i);
-                                const float a = fa[it & 1][i - i0][e], b = B[PW][s >> 1][s & 1];
+                                const float a = fa[it & 1][i - i0][e], b = Bc[s >> 2][2 * (s & 1) + ((s >> 1) & 1)];   // slot s = 2u + mf, u = 2j + (u & 1)
                                 if constexpr ((ABL & 128) != 0) {
                                     if constexpr (PW == 0 && s == 0) acc[tid][0] = a * b;
                                     else acc[tid][0] += a * b;
@@ -222,14 +222,17 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
                         if constexpr (it + 2 < NI) frag_req(std::integral_constant<unsigned, MASK>{}, std::integral_constant<int, it + 2>{}, sl);
                         else frag_req(std::integral_constant<unsigned, NEXT>{}, std::integral_constant<int, it + 2 - NI>{}, slot_of(1));
                         // this item's share of the phase's memory traffic: piece k of slice t+2 (in registers since the last phase) goes to
-                        // the ring and its registers take piece k of slice t+3; 8 / NI octets of position Q
+                        // the ring and its registers take piece k of slice t+3
                         if constexpr (it % (NI / 4) == 0 && (ABL & 2) == 0) {
                             constexpr int kp = it / (NI / 4);
                             lds_w[ws * (TR_SLICE / 16) + kp * 64] = wreg[kp];
                             wreg[kp] = buf_ld16(wb, lane_w + kp * 1024, (unsigned)((t + 3) * TR_SLICE + wave * 4096));
                         }
-#pragma unroll
-                        for (int u = it * (8 / NI); u < (it + 1) * (8 / NI); ++u) reload1(Q, u, qpos);
+                        // the next position's four quads, requested between the MFMA runs of the first half of the phase
+                        tr_static_for<4>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            if constexpr (j * (NI / 2) / 4 == it) reload1(j, qpos);
+                        });
                         __builtin_amdgcn_sched_barrier(0);
                     });
                     ++t;
