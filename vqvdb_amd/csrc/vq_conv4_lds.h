@@ -9,7 +9,7 @@
 // fragments, one 1 KiB buffer load per 13 MFMAs:
 //
 //   LDS: ring of FOUR plane slots of 32 KB ([pos 16][quad 8][leaf 16] float4), plane P of the workgroup's plane stream in slot P & 3;
-//        24 KB exchange buffer for the block statistics.  GroupNorm + ReLU is applied ONCE per element, on the way into LDS
+//        32 KB exchange buffer for the block statistics.  GroupNorm + ReLU is applied ONCE per element, on the way into LDS
 //        (the row kernel re-applies it on each of the 6.25 loads: 2.5 % of its time, tools/ablate/conv_rows16_ablate.hip ABL 16).
 //   per output plane P:  barrier | plane P+2 (prefetched during plane P-1) -> slot of plane P-2 | global loads of plane P+3 |
 //                        taps kd = 0 (plane P-1), 1 (plane P), 2 (plane P+1) | epilogue
@@ -22,14 +22,13 @@
 // ascending, inside a block "P16": conv_rows16_k's arithmetic and the oracle's, bit for bit.  Border rows (oh = 0, 3: two of three
 // kh) share a SIMD with inner rows (waves w and w+4 of a workgroup land on one SIMD), so every SIMD carries the same MFMA work.
 //
-// Statistics: one output row = one block of the 16-block contract.  A wave keeps the block sums of its four rows (od = 0..3) in
-// registers; at the end of a half tile the waves oh = 1..3 pass theirs through LDS to the wave oh = 0 of their cout tile, which adds
-// the sixteen in block order (GnAcc::fold's chain) after the next plane's barrier and finishes mean / rstd (STATS, conv1) or the
-// channel sums (CSUM, conv2).
+// Statistics: one output row = one block of the 16-block contract.  A wave passes the block sums of its rows through LDS to the wave
+// oh = 0 of its cout tile, which adds the sixteen in block order (GnAcc::fold's chain) after the first barrier of the next half tile and
+// finishes mean / rstd (STATS, conv1) or the channel sums (CSUM, conv2).
 #pragma once
 #include "vq_conv8_lds.h"
 
-constexpr size_t LDS_CONV4 = (size_t)4 * 2048 * 16 + (size_t)2 * 3 * 4 * 2 * 64 * 8;   // 131 072 + 24 576 B
+constexpr size_t LDS_CONV4 = (size_t)4 * 2048 * 16 + (size_t)2 * 4 * 4 * 2 * 64 * 8;   // 131 072 + 32 768 B = all 160 KB
 
 // ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads, 32 no MFMAs
 // STG: who stages the planes.  0: every wave two positions, the two waves of a SIMD at different points of the plane.  1: only the four
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
     static_assert(!(STATS && CSUM), "conv1 carries GroupNorm statistics, conv2 channel sums");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4* slots = (f32x4*)smem_raw;                                   // [4][16 pos][8 quads][16 leaves]
-    unsigned char* xch = smem_raw + (size_t)4 * 2048 * 16;              // [mt 2][oh-1 3][od 4][2][64 lanes] x 8 bytes
+    unsigned char* xch = smem_raw + (size_t)4 * 2048 * 16;              // [mt 2][oh 4][od 4][2][64 lanes] x 8 bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, j16 = lane & 15;
@@ -170,20 +169,23 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
     };
 
     // block sums of this wave's four rows of the current half tile
-    double bs[STATS ? 4 : 1], bq[STATS ? 4 : 1];
-    f32x4 cb4[CSUM ? 4 : 1];
+    // A row's block travels through LDS ([mt 2][oh 4][od 4] slots) to the wave oh = 0 of its cout tile, which reads the sixteen after
+    // the first barrier of the NEXT half tile.  The block of plane od is written one plane late (at the end of plane od + 1; od = 3: at
+    // once), so no slot of the next half tile is written before that reader's plane is over: one block in registers, not four.
+    double hold_s = 0.0, hold_q = 0.0;
+    f32x4 hold_c = {0.0f, 0.0f, 0.0f, 0.0f};
     // the ordered sum over the sixteen blocks of half tile hh (wave oh = 0 of each cout tile; the others' blocks come through LDS)
     auto finish_stats = [&](int hh) __attribute__((always_inline)) {
         if (oh != 0) return;   // (wave-uniform)
         const int tile = hh >> 1, jj = j16 + 16 * (hh & 1);
         if (STATS) {
-            const double* xs = (const double*)xch + (size_t)mt * 3 * 4 * 2 * 64;
+            const double* xs = (const double*)xch + (size_t)mt * 4 * 4 * 2 * 64;
             double S = 0.0, Q = 0.0;
 #pragma unroll
             for (int blk = 0; blk < 16; ++blk) {
                 const int o = blk & 3, d = blk >> 2;
-                S += o == 0 ? bs[d] : xs[(((o - 1) * 4 + d) * 2 + 0) * 64 + lane];
-                Q += o == 0 ? bq[d] : xs[(((o - 1) * 4 + d) * 2 + 1) * 64 + lane];
+                S += xs[((o * 4 + d) * 2 + 0) * 64 + lane];
+                Q += xs[((o * 4 + d) * 2 + 1) * 64 + lane];
             }
             float m, r;
             gn_finish(S, Q, 1.0 / 256.0, m, r);   // GroupNorm(8,32): 4 channels x 64 positions
@@ -191,12 +193,12 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
             A.out_rstd[((size_t)tile * 8 + 4 * mt + q4) * 32 + jj] = r;
         }
         if (CSUM) {
-            const f32x4* xs = (const f32x4*)xch + (size_t)mt * 3 * 4 * 64;
+            const f32x4* xs = (const f32x4*)xch + (size_t)mt * 4 * 4 * 64;
             f32x4 cs = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int blk = 0; blk < 16; ++blk) {
                 const int o = blk & 3, d = blk >> 2;
-                cs = cs + (o == 0 ? cb4[d] : xs[((o - 1) * 4 + d) * 64 + lane]);
+                cs = cs + xs[(o * 4 + d) * 64 + lane];
             }
             const float v[4] = {cs.x, cs.y, cs.z, cs.w};
 #pragma unroll
@@ -291,28 +293,18 @@ __global__ __launch_bounds__(512, 1) void conv4_lds_k(ConvArgs A)
             for (int ow = 0; ow < 4; ++ow) t += acc[ow].x + acc[ow].w;
             if (t == 12345.678f) ((f32x4*)A.out)[tid] = acc[0];
         }
-        // this row's block: kept (wave oh = 0) or handed to the wave oh = 0 of this cout tile through LDS when the half tile is complete
+        // this row's block goes to LDS one plane late (see hold_*)
         if (STATS) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (d == od) bs[d] = st.bs, bq[d] = st.bq;   // (static index, wave-uniform predicate)
+            double* xs = (double*)xch + (size_t)mt * 4 * 4 * 2 * 64;
+            if (od > 0) xs[((oh * 4 + od - 1) * 2 + 0) * 64 + lane] = hold_s, xs[((oh * 4 + od - 1) * 2 + 1) * 64 + lane] = hold_q;
+            if (od == 3) xs[((oh * 4 + 3) * 2 + 0) * 64 + lane] = st.bs, xs[((oh * 4 + 3) * 2 + 1) * 64 + lane] = st.bq;
+            hold_s = st.bs, hold_q = st.bq;
         }
         if (CSUM) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (d == od) cb4[d] = csb;
-        }
-        if (od == 3 && oh != 0) {
-            if (STATS) {
-                double* xs = (double*)xch + (size_t)mt * 3 * 4 * 2 * 64;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) xs[(((oh - 1) * 4 + d) * 2 + 0) * 64 + lane] = bs[d], xs[(((oh - 1) * 4 + d) * 2 + 1) * 64 + lane] = bq[d];
-            }
-            if (CSUM) {
-                f32x4* xs = (f32x4*)xch + (size_t)mt * 3 * 4 * 64;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) xs[((oh - 1) * 4 + d) * 64 + lane] = cb4[d];
-            }
+            f32x4* xs = (f32x4*)xch + (size_t)mt * 4 * 4 * 64;
+            if (od > 0) xs[(oh * 4 + od - 1) * 64 + lane] = hold_c;
+            if (od == 3) xs[(oh * 4 + 3) * 64 + lane] = csb;
+            hold_c = csb;
         }
     }
     };

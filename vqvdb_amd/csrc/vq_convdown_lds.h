@@ -134,8 +134,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_down_lds_k(ConvArgs A)
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // block sums of this wave's two rows (od = g, g + 2) of the current half tile, per cout tile
-    double bs[2][MTW], bq[2][MTW];
+    // (the block sums of this wave's two rows (od = g, g + 2) go to LDS as each row completes: the readers come two barriers later at the earliest)
     auto finish_stats = [&](int hh) __attribute__((always_inline)) {   // the row (g, oh) = (0, 0) wave(s): the sixteen blocks of half tile hh in block order
         if (w8 != 0) return;
         const int tile = hh >> 1, jj = j16 + 16 * (hh & 1);
@@ -224,19 +223,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_down_lds_k(ConvArgs A)
             for (int ow = 0; ow < 4; ++ow) t += acc[ow][0].x + acc[ow][MTW - 1].w;
             if (t == 12345.678f) ((f32x4*)A.out)[tid] = acc[0][0];
         }
+        // this row's block: read by the (0, 0) waves after the first barrier of the next half tile (od = g completes at id = 2 + 2g, at
+        // least two barriers after that reader ran for the previous half tile)
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            if (od >> 1) bs[1][m] = st[m].bs, bq[1][m] = st[m].bq;
-            else bs[0][m] = st[m].bs, bq[0][m] = st[m].bq;
-        }
-        if (od >> 1) {   // this wave's second row: both of its blocks go to LDS (read by the (0, 0) waves after the next barrier)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    xch[(((wave * 2 + r) * MTW + m) * 2 + 0) * 64 + lane] = bs[r][m];
-                    xch[(((wave * 2 + r) * MTW + m) * 2 + 1) * 64 + lane] = bq[r][m];
-                }
+            xch[(((wave * 2 + (od >> 1)) * MTW + m) * 2 + 0) * 64 + lane] = st[m].bs;
+            xch[(((wave * 2 + (od >> 1)) * MTW + m) * 2 + 1) * 64 + lane] = st[m].bq;
         }
     }
     lds_barrier();

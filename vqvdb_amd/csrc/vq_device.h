@@ -16,6 +16,12 @@
 #include <stdint.h>
 #include <type_traits>
 
+// One target: every kernel of this library assumes gfx950 (160 KB of LDS per workgroup, its fp32 MFMA shapes, v_permlane32_swap, LDS-DMA
+// of 16 bytes per lane).  A multi-arch build would silently produce kernels that cannot launch; it stops here instead.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the kernels of this library are written for gfx950 (MI355X): build with --offload-arch=gfx950 only"
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -838,9 +838,6 @@ __global__ __launch_bounds__((rows4_threads<CIN, COUT>())) void wgrad_rows4_k(Wg
     constexpr int SDY = Q16 ? 48 : COUT + 4, SX = Q16 ? 48 : CIN + 4;
     // up to 76.8 KB of static LDS (the 128 <-> 64 channel layers): within gfx950's 160 KB per workgroup, above the 64 KB of every earlier CDNA part
     static_assert(sizeof(float) * 3 * 32 * (SDY + SX) <= 160 * 1024, "wgrad_rows4_k: LDS ring larger than a gfx950 workgroup may hold");
-#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
-#error "the kernels of this library are written for gfx950 (160 KB LDS per workgroup, its MFMA shapes): build with --offload-arch=gfx950"
-#endif
     __shared__ __attribute__((aligned(16))) float sdy[3][32][SDY];
     __shared__ __attribute__((aligned(16))) float sx[3][32][SX];
     // XCD-aware slice number: workgroup b is observed to run on XCD b % 8 (speed only); every XCD gets a contiguous range of slices, i.e. of

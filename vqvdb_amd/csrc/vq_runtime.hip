@@ -57,6 +57,9 @@ struct NameMap {
         std::string first;
         T second;
     };
+    NameMap() = default;
+    NameMap(const NameMap&) = delete;              // (a copy would have capacity == size: the next insertion would look like an overflow)
+    NameMap& operator=(const NameMap&) = delete;
     static constexpr size_t kMaxNames = 1024;   // (the largest table, the device-buffer names of a training handle, holds ~250)
     std::vector<Ent> ents;
     std::vector<int> slots;   // index into ents, -1 = empty; size is a power of two > 2 * ents.size()
@@ -230,6 +233,7 @@ struct vqhip_codec {
     float *ft_P = nullptr, *ft_M = nullptr, *ft_V = nullptr;       // parameters, AdamW moments (device, flat)
     void* ft_refrag_jobs = nullptr;                                 // device job table of refrag_multi_k (vq_train_full.inc: refrag_all)
     int ft_refrag_n = 0, ft_refrag_wgs = 0;
+    const void* ft_refrag_P = nullptr;                              // the parameter block the cached job table points into
     char* ft_ws = nullptr;                                         // training workspace (saved activations, gradients)
     int64_t ft_tiles = 0;
     char* ft_part = nullptr;                                       // partial-gradient scratch

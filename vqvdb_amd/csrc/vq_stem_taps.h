@@ -82,10 +82,12 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
     // costs register pairs the accumulators need)
     const vq_buf tb = buf_of(A.T);
     const unsigned lane_t = (unsigned)((lane >> 3) * 64 + (lane & 7) * 4) * 4u;
+    // vector-memory operations per wave the RELAX wait below counts on: DMA instructions per slice, output stores per pass
+    constexpr int DMA_PER_SLICE = 4, STORES_PER_PASS = 8 * 4;
     auto issue_slice = [&](int t, int half, int slot) {
         if (ABL & 4) return;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < DMA_PER_SLICE; ++k) {
             const int i = k * 8 + wave;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tb, (__attribute__((address_space(3))) void*)(ring + slot * 2048 + i * 64), 16, (int)lane_t,
                                                  (int)(((unsigned)t * 16384u + (unsigned)i * 512u + (unsigned)half * 32u) * 4u), 0, 0);
@@ -136,6 +138,9 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                     // three slices of a pass were requested before the previous pass's epilogue, whose stores are younger: wait for all)
                     // RELAX: slices 0-2 were requested BEFORE the previous pass's 32 output stores per wave: "all but the youngest 8 + 32"
                     if (RELAX && t <= 2) {
+                        // vmcnt(2 younger slices + the pass's stores): the epilogue below must issue exactly STORES_PER_PASS stores per wave
+                        // (unconditional, one per (row, pw)) between the requests of slices 0-2 and this wait
+                        static_assert(2 * DMA_PER_SLICE + STORES_PER_PASS == 40, "the RELAX wait is vmcnt(40): update the immediate with the counts");
                         if (after_stores && !A.ystem_dbg) __builtin_amdgcn_s_waitcnt(0x8F78);   // vmcnt(40)
                         else if (t == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
                         else __builtin_amdgcn_s_waitcnt(0x0F78);
@@ -307,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void stem_taps_k(StemFusedArgs A)
                 const vq_buf outb = buf_of((const f32x4*)A.d2 + (size_t)tile * 64 * 16 * 32);
                 const vq_buf dbgb = buf_of(A.ystem_dbg ? (const f32x4*)A.ystem_dbg + (size_t)tile * 64 * 16 * 32 : (const f32x4*)A.d2);
                 const unsigned lane_o = (unsigned)(cg * 32 + jt) * 16u;
+                static_assert(STORES_PER_PASS == 8 * 4, "one output store per (row, pw): the RELAX wait of the tap loop counts them");
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     GnAcc st;

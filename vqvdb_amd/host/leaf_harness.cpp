@@ -8,13 +8,19 @@
 //   leaf_harness decompress <pack> <in.vqvdb>   <out.f32>   <batch>
 //   leaf_harness compress_stream   <pack> <leaves.f32> <out.vqvdb> <batch>   (vqhip_compress_file: overlapped pipeline)
 //   leaf_harness decompress_stream <pack> <in.vqvdb>   <out.f32>   <batch>   (vqhip_decompress_file)
-//   leaf_harness loopbench  <pack> <n_leaves> <tmp.vqvdb> <batch>[,<batch>...]   (both loops, timed per phase, synthetic leaves)
+//   leaf_harness loopbench  <pack> <n_leaves> <tmp.vqvdb> <batch>[,<batch>...] [threads]   (both loops, timed per phase, synthetic leaves;
+//                           threads: pack loop and leaf copies on that many threads, 0 = half the cores, like the reference's tbb::parallel_for)
 //   leaf_harness errors     <pack>
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
 //   leaf_harness readcheck  <ref_writer_v3.vqvdb> <batch>   (no GPU needed: StreamReader over the file the reference's writer wrote)
 //   leaf_harness makefile   <out.vqvdb> <n_leaves> (synthetic indices; config-3 input)
 #define VQVDB_HIP_STANDALONE
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -309,7 +315,60 @@ int readcheck(const std::string& path, size_t batch) {
 //   decompress (VQVAECodec.cpp:137-208): per batch { nextBatch | backend->decode (fresh zero-filled Tensor) | per-leaf memcpy into a 2 KiB leaf buffer }
 // One backend per batch size (the SOP node cache keeps it across cooks, SOP_VQVDB_Encoder.hpp:43-50); the first call of each
 // direction (lazy device allocations) is reported separately and excluded from the per-call figures, not from the totals.
-int loopbench(const std::string& pack, size_t total, const std::string& tmp, const std::string& batches) {
+// A fixed set of worker threads that split [0, n) into equal ranges: what tbb::parallel_for gives the reference's pack loop and leaf
+// copies (VQVAECodec.cpp:50,182) on hardware_concurrency() / 2 cores, without TBB.  Ranges under 256 leaves run on the caller.
+class RangePool {
+public:
+	explicit RangePool(unsigned workers) {
+		for (unsigned w = 0; w + 1 < workers; ++w) th_.emplace_back([this, w] { loop(w); });
+	}
+	~RangePool() {
+		{ std::lock_guard<std::mutex> lk(mu_); quit_ = true; ++gen_; }
+		cv_.notify_all();
+		for (auto& t : th_) t.join();
+	}
+	unsigned size() const { return static_cast<unsigned>(th_.size()) + 1; }
+	template <typename F> void run(size_t n, F&& f) {
+		const size_t parts = std::min<size_t>(size(), (n + 255) / 256);
+		if (parts <= 1) { f(size_t(0), n); return; }
+		fn_ = [&](size_t a, size_t b) { f(a, b); };
+		{ std::lock_guard<std::mutex> lk(mu_); n_ = n; parts_ = parts; left_ = parts - 1; ++gen_; }
+		cv_.notify_all();
+		f((parts - 1) * n / parts, n);            // the caller takes the last range
+		std::unique_lock<std::mutex> lk(mu_);
+		done_.wait(lk, [this] { return left_ == 0; });
+	}
+private:
+	void loop(unsigned w) {
+		uint64_t seen = 0;
+		for (;;) {
+			size_t n, parts;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] { return gen_ != seen; });
+				seen = gen_;
+				if (quit_) return;
+				n = n_, parts = parts_;
+			}
+			if (w + 1 < parts) {
+				fn_(w * n / parts, (w + 1) * n / parts);
+				std::lock_guard<std::mutex> lk(mu_);
+				if (--left_ == 0) done_.notify_one();
+			}
+		}
+	}
+	std::vector<std::thread> th_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_;
+	std::function<void(size_t, size_t)> fn_;
+	size_t n_ = 0, parts_ = 0, left_ = 0;
+	uint64_t gen_ = 0;
+	bool quit_ = false;
+};
+
+int loopbench(const std::string& pack, size_t total, const std::string& tmp, const std::string& batches, unsigned threads) {
+	RangePool pool(std::max(1u, threads));
+	const char* tag = threads > 1 ? "loopbench-mt" : "loopbench";
 	constexpr size_t BASE = 65536;
 	std::vector<float> base(std::min(total, BASE) * LEAF_VOXELS);
 	uint32_t x = 2463534242u;
@@ -339,10 +398,12 @@ int loopbench(const std::string& pack, size_t total, const std::string& tmp, con
 				const auto t0 = clk::now();
 				std::vector<float> hostData(B * LEAF_VOXELS);
 				std::vector<vqvdb::Coord3i> origins(B);
-				for (size_t i = 0; i < B; ++i) {
-					origins[i] = originOf(start + i);
-					std::memcpy(hostData.data() + i * LEAF_VOXELS, base.data() + ((start + i) % nbase) * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
-				}
+				pool.run(B, [&](size_t lo, size_t hi) {
+					for (size_t i = lo; i < hi; ++i) {
+						origins[i] = originOf(start + i);
+						std::memcpy(hostData.data() + i * LEAF_VOXELS, base.data() + ((start + i) % nbase) * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
+					}
+				});
 				TensorView view;
 				view.data = hostData.data();
 				view.shape = {static_cast<int64_t>(B), 1, 8, 8, 8};
@@ -360,8 +421,8 @@ int loopbench(const std::string& pack, size_t total, const std::string& tmp, con
 		}
 		const double wallC = ms(c0, clk::now());
 		const double nc = calls > 1 ? double(calls - 1) : 1.0;
-		std::printf("loopbench compress   batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: pack %.4f ms, encode %.4f ms, frame+write %.4f ms\n",
-		            batch, total, wallC, total / wallC / 1e3, first, tPack / nc, tCall / nc, tWrite / nc);
+		std::printf("%s compress   batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: pack %.4f ms, encode %.4f ms, frame+write %.4f ms\n",
+		            tag, batch, total, wallC, total / wallC / 1e3, first, tPack / nc, tCall / nc, tWrite / nc);
 		if (leafStore.empty()) {
 			leafStore.resize((total + BASE - 1) / BASE);
 			for (size_t i = 0; i < leafStore.size(); ++i) { leafStore[i].reset(new float[BASE * LEAF_VOXELS]); std::memset(leafStore[i].get(), 0, BASE * LEAF_VOXELS * sizeof(float)); }
@@ -389,10 +450,12 @@ int loopbench(const std::string& pack, size_t total, const std::string& tmp, con
 					const Tensor decoded = backend->decode(view);
 					const auto t2 = clk::now();
 					const float* src = decoded.getData<float>();
-					for (size_t i = 0; i < B; ++i) {  // stand-in for touchLeaf + memcpy + setValuesOn (VQVAECodec.cpp:182-192)
-						const size_t j = leafNo + i;
-						std::memcpy(leafStore[j / BASE].get() + (j % BASE) * LEAF_VOXELS, src + i * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
-					}
+					pool.run(B, [&](size_t lo, size_t hi) {
+						for (size_t i = lo; i < hi; ++i) {  // stand-in for touchLeaf + memcpy + setValuesOn (VQVAECodec.cpp:182-192)
+							const size_t j = leafNo + i;
+							std::memcpy(leafStore[j / BASE].get() + (j % BASE) * LEAF_VOXELS, src + i * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
+						}
+					});
 					const auto t3 = clk::now();
 					if (calls == 0) first = ms(t1, t2);
 					else tRead += ms(t0, t1), tDec += ms(t1, t2), tCopy += ms(t2, t3);
@@ -403,7 +466,8 @@ int loopbench(const std::string& pack, size_t total, const std::string& tmp, con
 		}
 		const double wallD = ms(d0, clk::now());
 		const double nd = calls > 1 ? double(calls - 1) : 1.0;
-		std::printf("loopbench decompress batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: read+deframe %.4f ms, decode %.4f ms, leaf copies %.4f ms\n",
+		std::printf("%s decompress batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: read+deframe %.4f ms, decode %.4f ms, leaf copies %.4f ms\n",
+		            tag,
 		            batch, leafNo, wallD, leafNo / wallD / 1e3, first, tRead / nd, tDec / nd, tCopy / nd);
 		if (leafNo != total) return 1;
 	}
@@ -454,7 +518,12 @@ int main(int argc, char** argv) {
 		if (mode == "compress_stream" && argc == 6) return compressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "decompress_stream" && argc == 6) return decompressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "errors" && argc == 3) return errors(argv[2]);
-		if (mode == "loopbench" && argc == 6) return loopbench(argv[2], std::stoul(argv[3]), argv[4], argv[5]);
+		if (mode == "loopbench" && argc == 6) return loopbench(argv[2], std::stoul(argv[3]), argv[4], argv[5], 1);
+		// ... with the pack loop and the leaf copies on N threads (0 = hardware_concurrency() / 2: what tbb::parallel_for uses in the reference)
+		if (mode == "loopbench" && argc == 7) {
+			const unsigned t = static_cast<unsigned>(std::stoul(argv[6]));
+			return loopbench(argv[2], std::stoul(argv[3]), argv[4], argv[5], t ? t : std::max(1u, std::thread::hardware_concurrency() / 2));
+		}
 		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
 		if (mode == "readcheck" && argc == 4) return readcheck(argv[2], std::stoul(argv[3]));
 		if (mode == "makefile" && argc == 4) return makefile(argv[2], std::stoul(argv[3]));

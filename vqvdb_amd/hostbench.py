@@ -57,7 +57,7 @@ def write_index_file(path: str, indices_fn, n: int, chunk: int = 1 << 20, name: 
             f.write(rec.tobytes())
 
 
-LOOP_RE = re.compile(r"loopbench (compress|decompress)\s+batch (\d+): (\d+) leaves in ([\d.]+) ms = ([\d.]+) M leaves/s \| first call ([\d.]+) ms \| "
+LOOP_RE = re.compile(r"loopbench(?:-mt)? (compress|decompress)\s+batch (\d+): (\d+) leaves in ([\d.]+) ms = ([\d.]+) M leaves/s \| first call ([\d.]+) ms \| "
                      r"per call: [\w+]+ ([\d.]+) ms, (?:encode|decode) ([\d.]+) ms, [\w+ ]+ ([\d.]+) ms")
 
 
@@ -72,17 +72,27 @@ def orchestrator_loop(harness: str, W: dict, tmpdir: str, n: int, batches=(64, 1
                        "(SOP_VQVDB_Encoder.cpp:33-38), and the backend's chunk 65536",
            "leaves": n, "batches": {}}
     try:
-        r = subprocess.run([harness, "loopbench", pk, str(n), tmp, ",".join(str(b) for b in batches)], capture_output=True, text=True, timeout=900)
-        if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-400:]}
-        for m in LOOP_RE.finditer(r.stdout):
-            leg, b = m.group(1), m.group(2)
-            names = ("pack_ms", "encode_ms", "frame_write_ms") if leg == "compress" else ("read_deframe_ms", "decode_ms", "leaf_copy_ms")
-            res["batches"].setdefault(b, {})[leg] = {
-                "leaves_per_s": round(float(m.group(5)) * 1e6, 1), "wall_s": round(float(m.group(4)) / 1e3, 4), "first_call_ms": float(m.group(6)),
-                "per_call": dict(zip(names, (float(m.group(7)), float(m.group(8)), float(m.group(9)))))}
-        if not res["batches"]:
-            return {"error": "no loopbench lines parsed: " + r.stdout[-300:]}
+        def one(extra, into):
+            r = subprocess.run([harness, "loopbench", pk, str(n), tmp, ",".join(str(b) for b in batches)] + extra, capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                return {"error": (r.stderr or r.stdout)[-400:]}
+            for m in LOOP_RE.finditer(r.stdout):
+                leg, b = m.group(1), m.group(2)
+                names = ("pack_ms", "encode_ms", "frame_write_ms") if leg == "compress" else ("read_deframe_ms", "decode_ms", "leaf_copy_ms")
+                into.setdefault(b, {})[leg] = {
+                    "leaves_per_s": round(float(m.group(5)) * 1e6, 1), "wall_s": round(float(m.group(4)) / 1e3, 4), "first_call_ms": float(m.group(6)),
+                    "per_call": dict(zip(names, (float(m.group(7)), float(m.group(8)), float(m.group(9)))))}
+            return None if into else {"error": "no loopbench lines parsed: " + r.stdout[-300:]}
+        err = one([], res["batches"])
+        if err:
+            return err
+        # ... and with the pack loop and the leaf copies on half the cores, as tbb::parallel_for runs them in the reference (VQVAECodec.cpp:50,182)
+        threads = max(1, (os.cpu_count() or 2) // 2)
+        res["threaded"] = {"threads": threads, "note": "same loops, pack / leaf-copy ranges of >= 256 leaves split over a fixed pool of std::threads "
+                           "(hardware_concurrency() / 2); batches below 512 leaves run on the caller either way", "batches": {}}
+        err = one([str(threads)], res["threaded"]["batches"])
+        if err:
+            res["threaded"] = err
     finally:
         os.unlink(pk)
         if os.path.exists(tmp):
