@@ -130,10 +130,11 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
             Bc[j] = (f32x4){__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r1.x), __uint_as_float(r1.y)};
         }
     };
-    // weights: slice t at t*TR_SLICE; this wave moves bytes [wave*4096, +4096) of every slice
+    // weights: slice t at t*TR_SLICE; this wave moves the 1 KB pieces wave, wave + 8, .. of a slice, as many as cover the slice's N tile
+    // blocks (ceil(N / 2) of 4: a slice of 3 .. 7 blocks is not copied as if it had 8; the count is a compile-time constant per phase)
     const vq_buf wb = buf_of(A.wfrag);
     const unsigned lane_w = (unsigned)lane * 16u;
-    f32x4* const lds_w = (f32x4*)(smem_raw + wave * 4096) + lane;   // + slot*TR_SLICE/16 + j*64
+    f32x4* const lds_w = (f32x4*)(smem_raw + wave * 1024) + lane;   // + slot*TR_SLICE/16 + kp*512
     const f32x4* const lds_r = (const f32x4*)smem_raw + lane;       // + slot*TR_SLICE/16 + (tile i*4 + g)*64
     const vq_buf outb = buf_of(A.out + (size_t)tile * 32 * 512);
     const float* bias = A.bias_frag;   // plain per voxel [512]
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_w[s * (TR_SLICE / 16) + j * 64] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(s * TR_SLICE + wave * 4096));
+        for (int j = 0; j < 4; ++j) lds_w[s * (TR_SLICE / 16) + j * 512] = buf_ld16(wb, lane_w + j * 8192, (unsigned)(s * TR_SLICE + wave * 1024));
     f32x4 wreg[4];   // this wave's share of the slice two phases ahead: loaded in phase t-1, written to the ring in phase t
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 1024, (unsigned)(2 * TR_SLICE + wave * 4096));
+    for (int j = 0; j < 4; ++j) wreg[j] = buf_ld16(wb, lane_w + j * 8192, (unsigned)(2 * TR_SLICE + wave * 1024));
 #pragma unroll
     for (int j = 0; j < 4; ++j) reload1(j, 0);   // unit 0 starts at plane 0, row 0, position 0
     __builtin_amdgcn_s_waitcnt(0x0f70);               // enter the loops with nothing in flight
@@ -225,8 +226,12 @@ __global__ __launch_bounds__(512, 2) void tail_rows16_k(ConvArgs A)
                         // the ring and its registers take piece k of slice t+3
                         if constexpr (it % (NI / 4) == 0 && (ABL & 2) == 0) {
                             constexpr int kp = it / (NI / 4);
-                            lds_w[ws * (TR_SLICE / 16) + kp * 64] = wreg[kp];
-                            wreg[kp] = buf_ld16(wb, lane_w + kp * 1024, (unsigned)((t + 3) * TR_SLICE + wave * 4096));
+                            // pieces per wave of slices t+2 / t+3: ceil(N / 2) while the slice lies in this plane (its N is static), all four
+                            // behind it (the next plane's first row, or another unit's)
+                            constexpr int q2 = PH * 4 + PW + 2, q3 = PH * 4 + PW + 3;
+                            constexpr int c2 = q2 < 16 ? (tr_popc(tr_mask(PAIR, q2 / 4)) + 1) / 2 : 4, c3 = q3 < 16 ? (tr_popc(tr_mask(PAIR, q3 / 4)) + 1) / 2 : 4;
+                            if constexpr (kp < c2) lds_w[ws * (TR_SLICE / 16) + kp * 512] = wreg[kp];
+                            if constexpr (kp < c3) wreg[kp] = buf_ld16(wb, lane_w + kp * 8192, (unsigned)((t + 3) * TR_SLICE + wave * 1024));
                         }
                         // the next position's four quads, requested between the MFMA runs of the first half of the phase
                         tr_static_for<4>([&](auto jc) {
