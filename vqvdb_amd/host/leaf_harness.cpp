@@ -316,7 +316,7 @@ int readcheck(const std::string& path, size_t batch) {
 // One backend per batch size (the SOP node cache keeps it across cooks, SOP_VQVDB_Encoder.hpp:43-50); the first call of each
 // direction (lazy device allocations) is reported separately and excluded from the per-call figures, not from the totals.
 // A fixed set of worker threads that split [0, n) into equal ranges: what tbb::parallel_for gives the reference's pack loop and leaf
-// copies (VQVAECodec.cpp:50,182) on hardware_concurrency() / 2 cores, without TBB.  Ranges under 256 leaves run on the caller.
+// copies (VQVAECodec.cpp:50,182) on hardware_concurrency() / 2 cores, without TBB.  Batches of up to 1024 leaves run on the caller.
 class RangePool {
 public:
 	explicit RangePool(unsigned workers) {
@@ -329,7 +329,7 @@ public:
 	}
 	unsigned size() const { return static_cast<unsigned>(th_.size()) + 1; }
 	template <typename F> void run(size_t n, F&& f) {
-		const size_t parts = std::min<size_t>(size(), (n + 255) / 256);
+		const size_t parts = std::min<size_t>(size(), (n + 1023) / 1024);   // (2 MB of leaves per range at least: waking the pool costs ~0.1 ms)
 		if (parts <= 1) { f(size_t(0), n); return; }
 		fn_ = [&](size_t a, size_t b) { f(a, b); };
 		{ std::lock_guard<std::mutex> lk(mu_); n_ = n; parts_ = parts; left_ = parts - 1; ++gen_; }

@@ -88,8 +88,8 @@ def orchestrator_loop(harness: str, W: dict, tmpdir: str, n: int, batches=(64, 1
             return err
         # ... and with the pack loop and the leaf copies on half the cores, as tbb::parallel_for runs them in the reference (VQVAECodec.cpp:50,182)
         threads = max(1, (os.cpu_count() or 2) // 2)
-        res["threaded"] = {"threads": threads, "note": "same loops, pack / leaf-copy ranges of >= 256 leaves split over a fixed pool of std::threads "
-                           "(hardware_concurrency() / 2); batches below 512 leaves run on the caller either way", "batches": {}}
+        res["threaded"] = {"threads": threads, "note": "same loops, pack / leaf-copy ranges of >= 1024 leaves split over a fixed pool of std::threads "
+                           "(hardware_concurrency() / 2); batches of up to 1024 leaves run on the caller either way", "batches": {}}
         err = one([str(threads)], res["threaded"]["batches"])
         if err:
             res["threaded"] = err
