@@ -58,6 +58,22 @@ def test_training_step_bit_exact_vs_oracle(tcodec, oracle, weights):
             assert np.array_equal(_bits(got[k]), _bits(state[k])), (step, k)
 
 
+def test_statistics_kernels_agree(weights, monkeypatch):
+    """The codebook statistics come from per-(segment, code) member lists (vq_ema_lists_k + vq_ema_gather_k, the default) or from every
+    (code, segment) wave scanning the segment's indices (VQHIP_TRAIN_EMA=scan, rounds 1-4): the same sums in the same order, bit for bit —
+    on a batch whose codes are badly skewed (sparse leaves: a few codes own thousands of rows of a segment, most own none) and on ragged sizes."""
+    batches = [np.concatenate([synth.sparse_leaves(3000, seed=5), synth.make_leaves(2003, seed=6)]), synth.make_leaves(129, seed=7), synth.make_leaves(1, seed=8)]
+    got = {}
+    for mode in ("lists", "scan"):
+        monkeypatch.setenv("VQHIP_TRAIN_EMA", mode)
+        c = HipCodec(weightpack.dumps(weights))
+        c.train_begin()
+        got[mode] = [_gpu_stats(c, b)[0].cpu().numpy() for b in batches]
+        c.close()
+    for a, b in zip(got["lists"], got["scan"]):
+        assert a[:K].sum() > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_training_matches_reference_golden(tcodec, weights, gt):  # noqa: F811
     keep = {}
 

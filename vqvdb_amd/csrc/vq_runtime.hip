@@ -247,6 +247,7 @@ struct vqhip_codec {
     size_t ft_ev_next = 0;
     bool train_wgrad_rows = true;    // training backward: weight gradients of the k3 layers at 4^3 by wgrad_rows4_k (VQHIP_TRAIN_WGRAD=pairs: wgrad32_k)
     bool train_stem_lut = true;      // training forward: decoder stem through the (tap, code) table rebuilt every step (VQHIP_TRAIN_STEM=conv: the real conv)
+    bool train_ema_lists = true;     // codebook statistics from per-(segment, code) member lists (vq_ema_lists_k + vq_ema_gather_k); VQHIP_TRAIN_EMA=scan: every (code, segment) wave scans the indices
     bool train_folded_tail = true;   // training step: up_conv + PixelShuffle3D + final as one folded operator (vq_train_tail.h); VQHIP_TRAIN_TAIL=unfolded keeps the layer-by-layer tail
     float* z4_out = nullptr;   // set around encode_chunk by the training forward: latent also in the L4 layout
     char* tr_part = nullptr;   // per-(code, row segment) partial statistics
@@ -1831,6 +1832,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_TRAIN_BIAS")) c->train_bias_main = std::strcmp(e, "side") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "gather") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_EMA")) c->train_ema_lists = std::strcmp(e, "scan") != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->err = "hipStreamCreate failed";
         return bail(VQHIP_ERR_DEVICE);
@@ -2215,6 +2217,44 @@ int vqhip_train_begin(vqhip_codec* c, const float* cluster_size, const float* em
     return VQHIP_OK;
 }
 
+// scratch of the codebook statistics (tr_part): per-(code, segment) partial sums, squared errors and counts, then the per-segment member
+// lists of vq_ema_lists_k and their (start, count) table
+struct EmaScratch {
+    float* part;
+    double* sqpart;
+    int* cntpart;
+    unsigned short* lists;
+    int* starts;
+};
+size_t ema_scratch_bytes(int n_seg)
+{
+    return (size_t)256 * n_seg * (128 * sizeof(float) + sizeof(double) + sizeof(int)) + (size_t)n_seg * VQ_SEG_ROWS * sizeof(unsigned short) +
+           (size_t)n_seg * 256 * 2 * sizeof(int);
+}
+EmaScratch ema_scratch(char* base, int n_seg)
+{
+    EmaScratch e;
+    e.part = reinterpret_cast<float*>(base);
+    e.sqpart = reinterpret_cast<double*>(base + (size_t)256 * n_seg * 128 * sizeof(float));
+    e.cntpart = reinterpret_cast<int*>(base + (size_t)256 * n_seg * (128 * sizeof(float) + sizeof(double)));
+    e.lists = reinterpret_cast<unsigned short*>(base + (size_t)256 * n_seg * (128 * sizeof(float) + sizeof(double) + sizeof(int)));
+    e.starts = reinterpret_cast<int*>(reinterpret_cast<char*>(e.lists) + (size_t)n_seg * VQ_SEG_ROWS * sizeof(unsigned short));
+    return e;
+}
+// encodings_sum / dw / squared error of one batch into `stats` (VQ_STATS_* layout): member lists per (segment, code), ordered partial sums,
+// ordered reduction.  VQHIP_TRAIN_EMA=scan: every (code, segment) wave scans the segment's indices itself (rounds 1-4; the same bits)
+void launch_vq_ema(vqhip_codec* c, hipStream_t s, const float* z, const uint8_t* idx, int64_t rows, int n_seg, float* stats)
+{
+    const EmaScratch e = ema_scratch(c->tr_part, n_seg);
+    if (c->train_ema_lists) {
+        hipLaunchKernelGGL(vq_ema_lists_k, dim3(n_seg), dim3(64), 0, s, idx, rows, e.lists, e.starts);
+        hipLaunchKernelGGL(vq_ema_gather_k, dim3(256, (n_seg + 15) / 16), dim3(1024), 0, s, z, e.lists, e.starts, c->dw["cb"], rows, n_seg, e.part, e.sqpart, e.cntpart);
+    } else {
+        hipLaunchKernelGGL(vq_ema_partials_k, dim3(256, (n_seg + 15) / 16), dim3(1024), 0, s, z, idx, c->dw["cb"], rows, n_seg, e.part, e.sqpart, e.cntpart);
+    }
+    hipLaunchKernelGGL(vq_ema_reduce_k, dim3(256), dim3(128), 0, s, e.part, e.sqpart, e.cntpart, rows, n_seg, stats);
+}
+
 int vqhip_train_vq_stats_device(vqhip_codec* c, const float* d_leaves, int64_t n, float* d_stats, uint8_t* d_idx, float* d_latent, void* stream)
 {
     if (!c) return VQHIP_ERR_INVALID;
@@ -2233,7 +2273,7 @@ int vqhip_train_vq_stats_device(vqhip_codec* c, const float* d_leaves, int64_t n
         c->tr_leaves = n;
     }
     {
-        const size_t need = (size_t)256 * ((n * 64 + VQ_SEG_ROWS - 1) / VQ_SEG_ROWS) * (128 * sizeof(float) + sizeof(double) + sizeof(int));
+        const size_t need = ema_scratch_bytes((int)((n * 64 + VQ_SEG_ROWS - 1) / VQ_SEG_ROWS));
         if (c->tr_part_bytes < need) {
             HIPCHK(c, hipStreamSynchronize(s));
             if (c->tr_part) hipFree(c->tr_part);
@@ -2248,14 +2288,8 @@ int vqhip_train_vq_stats_device(vqhip_codec* c, const float* d_leaves, int64_t n
     if (rc) return rc;
     const int64_t rows = n * 64;
     const int n_seg = (int)((rows + VQ_SEG_ROWS - 1) / VQ_SEG_ROWS);
-    float* part = reinterpret_cast<float*>(c->tr_part);
-    double* sqpart = reinterpret_cast<double*>(c->tr_part + (size_t)256 * n_seg * 128 * sizeof(float));
-    int* cntpart = reinterpret_cast<int*>(c->tr_part + (size_t)256 * n_seg * (128 * sizeof(float) + sizeof(double)));
     Launcher L{c, s, n};
-    L.run("train_vq_ema_partials", [&] {
-        hipLaunchKernelGGL(vq_ema_partials_k, dim3(256, (n_seg + 15) / 16), dim3(1024), 0, s, z, idx, c->dw["cb"], rows, n_seg, part, sqpart, cntpart);
-    });
-    L.run("train_vq_ema_reduce", [&] { hipLaunchKernelGGL(vq_ema_reduce_k, dim3(256), dim3(128), 0, s, part, sqpart, cntpart, rows, n_seg, d_stats); });
+    L.run("train_vq_ema_stats", [&] { launch_vq_ema(c, s, z, idx, rows, n_seg, d_stats); });
     return L.rc;
 }
 

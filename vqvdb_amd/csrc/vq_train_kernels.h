@@ -236,6 +236,103 @@ __global__ __launch_bounds__(1024) void vq_ema_partials_k(const float* __restric
     }
 }
 
+// Round 5: the same partial sums without every (code, segment) wave walking the segment's 8192 index bytes (256 x the index traffic,
+// and a dependent ballot -> gather chain per 64 rows: 0.19 ms at 2048 leaves, a quarter of the codebook-training step).
+//   vq_ema_lists_k   one wave per segment: a STABLE counting sort of the segment's rows by code (LDS histogram, exclusive scan, scatter
+//                    with each lane's rank among the equal codes of its 64-row chunk from eight ballots) -> per code the member rows of
+//                    the segment in ascending order (16-bit offsets inside the segment) + start / count per (segment, code)
+//   vq_ema_gather_k  one wave per (code, segment) as before, but its member rows are known up front: up to eight rows in flight, added in
+//                    ascending order — the arithmetic of vq_ema_partials_k, bit for bit (VQHIP_TRAIN_EMA=scan keeps that kernel)
+__global__ __launch_bounds__(64) void vq_ema_lists_k(const uint8_t* __restrict__ idx, int64_t n_rows, unsigned short* __restrict__ lists /*[n_seg][VQ_SEG_ROWS]*/,
+                                                     int* __restrict__ starts /*[n_seg][256][2]: start, count*/)
+{
+    __shared__ int cnt[256], off[256];
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int64_t r0 = (int64_t)seg * VQ_SEG_ROWS;
+    const int nr = (int)(r0 + VQ_SEG_ROWS < n_rows ? VQ_SEG_ROWS : n_rows - r0);
+    for (int i = lane; i < 256; i += 64) cnt[i] = 0;
+    __syncthreads();
+    for (int r = lane; r < nr; r += 64) atomicAdd(&cnt[idx[r0 + r]], 1);
+    __syncthreads();
+    {   // exclusive scan over the 256 codes: four codes per lane, then across the lanes
+        const int c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2], c3 = cnt[4 * lane + 3];
+        const int own = c0 + c1 + c2 + c3;
+        int incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const int base = incl - own;
+        off[4 * lane] = base, off[4 * lane + 1] = base + c0, off[4 * lane + 2] = base + c0 + c1, off[4 * lane + 3] = base + c0 + c1 + c2;
+        int* st = starts + ((size_t)seg * 256 + 4 * lane) * 2;
+        st[0] = base, st[1] = c0, st[2] = base + c0, st[3] = c1, st[4] = base + c0 + c1, st[5] = c2, st[6] = base + c0 + c1 + c2, st[7] = c3;
+    }
+    __syncthreads();
+    unsigned short* dst = lists + (size_t)seg * VQ_SEG_ROWS;
+    for (int rb = 0; rb < nr; rb += 64) {
+        const int r = rb + lane;
+        const bool live = r < nr;
+        const int code = live ? (int)idx[r0 + r] : 0;
+        // lanes of this chunk with the same code (and live): eight ballots
+        unsigned long long m = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((code >> b) & 1);
+            m &= ((code >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        const int base = off[code];                       // (every lane of the group reads it before the group's first lane advances it)
+        if (live) dst[base + rank] = (unsigned short)r;
+        if (live && rank == 0) off[code] = base + __popcll(m);
+        __syncthreads();                                  // (one wave: orders the LDS update before the next chunk's reads)
+    }
+}
+
+__global__ __launch_bounds__(1024) void vq_ema_gather_k(const float* __restrict__ z, const unsigned short* __restrict__ lists, const int* __restrict__ starts,
+                                                         const float* __restrict__ E, int64_t n_rows, int n_seg, float* __restrict__ part,
+                                                         double* __restrict__ sqpart, int* __restrict__ cntpart)
+{
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y * 16 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (seg >= n_seg) return;
+    const int64_t r0 = (int64_t)seg * VQ_SEG_ROWS;
+    const int start = starts[((size_t)seg * 256 + k) * 2], cnt = starts[((size_t)seg * 256 + k) * 2 + 1];
+    const unsigned short* lst = lists + (size_t)seg * VQ_SEG_ROWS + start;
+    const float e0 = E[k * 128 + 2 * lane], e1 = E[k * 128 + 2 * lane + 1];
+    float a0 = 0.0f, a1 = 0.0f, sq = 0.0f;
+    for (int b0 = 0; b0 < cnt; b0 += 64) {
+        const int nb = cnt - b0 < 64 ? cnt - b0 : 64;
+        const int mine = lane < nb ? (int)lst[b0 + lane] : 0;   // this batch's member rows, one per lane
+        for (int j0 = 0; j0 < nb; j0 += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = __builtin_amdgcn_readlane(mine, (j0 + i) & 63);
+                if (j0 + i < nb) v[i] = *(const float2*)(z + (size_t)(r0 + r) * 128 + 2 * lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (j0 + i < nb) {
+                    a0 = a0 + v[i].x;
+                    a1 = a1 + v[i].y;
+                    const float d0 = v[i].x - e0, d1 = v[i].y - e1;
+                    sq = __builtin_fmaf(d0, d0, sq);
+                    sq = __builtin_fmaf(d1, d1, sq);
+                }
+        }
+    }
+    float2* dst = (float2*)(part + ((size_t)k * n_seg + seg) * 128);
+    dst[lane] = make_float2(a0, a1);
+    double s = 0.0;
+    for (int l = 0; l < 64; ++l) s += (double)__shfl(sq, l, 64);
+    if (lane == 0) {
+        sqpart[(size_t)k * n_seg + seg] = s;
+        cntpart[(size_t)k * n_seg + seg] = cnt;
+    }
+}
+
 __global__ __launch_bounds__(128) void vq_ema_reduce_k(const float* __restrict__ part, const double* __restrict__ sqpart, const int* __restrict__ cntpart,
                                                         int64_t n_rows, int n_seg, float* __restrict__ stats)
 {
