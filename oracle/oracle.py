@@ -82,14 +82,17 @@ class Oracle:
             raise RuntimeError("oracle encode failed")
         return (idx, bufs) if debug else idx
 
-    def decode(self, idx: np.ndarray, threads: int = 1, debug=(), unfolded: bool = False):
+    def decode(self, idx: np.ndarray, threads: int = 1, debug=(), unfolded: bool = False, tail_skip_rows: bool = False):
         """unfolded=True runs the decoder tail layer by layer (up_conv -> pixel shuffle -> final) instead
-        of the folded composite the GPU uses; both are restatements of VQVAE_v2.py:265-275."""
+        of the folded composite the GPU uses; both are restatements of VQVAE_v2.py:265-275.
+        tail_skip_rows=True: the folded tail without the W-rows outside a voxel's reach in H (structurally zero weights), as the
+        GPU's full-chunk kernel runs it; the same bits for finite activations."""
+        assert not (unfolded and tail_skip_rows)
         idx = np.ascontiguousarray(idx, dtype=np.uint8).reshape(-1, 64)
         B = idx.shape[0]
         out = np.zeros((B, 512), dtype=np.float32)
         ptrs, bufs = self._dbg(B, set(debug))
-        rc = self.lib.vqo_decode_ex(self._wptr, idx.ctypes.data, B, out.ctypes.data, ptrs, threads, int(unfolded))
+        rc = self.lib.vqo_decode_ex(self._wptr, idx.ctypes.data, B, out.ctypes.data, ptrs, threads, 2 if tail_skip_rows else int(unfolded))
         if rc:
             raise RuntimeError("oracle decode failed")
         return (out, bufs) if debug else out

@@ -323,7 +323,10 @@ static tail_t* tail_build(const float* Wu /*[256][64][27]*/, const float* bu, co
 }
 static void tail_free(tail_t* T) { if (T) { free(T->wc); free(T); } }
 
-static void tail_apply(const tail_t* T, const float* in /*[64][64][LT]*/, float* pre /*[512][LT]*/)
+/* skip_rows != 0: W-rows (pd,ph) outside the voxel's reach in H (all of their composite weights are structurally zero) are not run at
+ * all — what the GPU's tail_rows16_k does per 16-voxel tile (round 5).  For finite activations their chain is fmaf(0,x,.) = +0 and
+ * acc + (+0) = acc (acc is never -0), so both forms give the same bits; tests/test_oracle_golden.py checks that on the CPU. */
+static void tail_apply_ex(const tail_t* T, const float* in /*[64][64][LT]*/, float* pre /*[512][LT]*/, int skip_rows)
 {
     int p8[64];
     korder_p8(64, p8);
@@ -335,7 +338,11 @@ static void tail_apply(const tail_t* T, const float* in /*[64][64][LT]*/, float*
         const int pd0 = c0 > 0 ? c0 - 1 : 0, pd1 = c1 < 3 ? c1 + 1 : 3;
         float acc[LT], row[LT];
         for (int l = 0; l < LT; ++l) acc[l] = 0.0f, row[l] = 0.0f;
+        const int oh = (ov >> 3) & 7;
+        const int h0 = (oh > 0 ? oh - 1 : 0) >> 1, h1 = (oh < 7 ? oh + 1 : 7) >> 1;
+        const int ph0 = h0 > 0 ? h0 - 1 : 0, ph1 = h1 < 3 ? h1 + 1 : 3;
         for (int p = pd0 * 16; p < (pd1 + 1) * 16; ++p) {
+            if (skip_rows && (((p >> 2) & 3) < ph0 || ((p >> 2) & 3) > ph1)) continue;
             const float* w = T->wc + (size_t)ov * 4096 + (size_t)p * 64;
             if ((p & 3) == 0)                                   /* a new W-row of input positions: fresh chain */
                 for (int l = 0; l < LT; ++l) row[l] = 0.0f;
@@ -697,8 +704,8 @@ static void decode_tile(const float* const* W, const uint8_t* idx, int64_t leaf0
     channel_attention(x6, x7, 64, W[W_D_FC0], W[W_D_FC2]);
     if (dbg) dump(dbg[DBG_D_X7], x7, 64, 64, leaf0, nl);
     float* pre = s->d; /* [1][512][LT] */
-    if (!unfolded) {
-        tail_apply(tail, x7, pre);
+    if (unfolded == 0 || unfolded == 2) {   /* 2: the folded tail with the rows outside a voxel's reach in H skipped */
+        tail_apply_ex(tail, x7, pre, unfolded == 2);
     } else {
         float* up = s->b; /* [256][64][LT] */
         conv3d(x7, up, W[W_D_UP_W], W[W_D_UP_B], 64, 256, 4, 4, 3, 1, 1, p8_64);
@@ -776,7 +783,8 @@ int vqo_encode_ex(const float* const* W, const float* leaves, int64_t B, uint8_t
     return err;
 }
 
-/* unfolded != 0: run the decoder tail layer by layer (up_conv, pixel shuffle, final) instead of folded */
+/* unfolded = 1: run the decoder tail layer by layer (up_conv, pixel shuffle, final) instead of folded; 2: folded, rows outside a voxel's
+ * reach in H skipped (tail_apply_ex) */
 int vqo_decode_ex(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads, int unfolded);
 
 int vqo_decode(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads)
@@ -787,7 +795,7 @@ int vqo_decode(const float* const* W, const uint8_t* idx, int64_t B, float* out,
 int vqo_decode_ex(const float* const* W, const uint8_t* idx, int64_t B, float* out, float* const* dbg, int nthreads, int unfolded)
 {
     if (B <= 0) return 0;
-    tail_t* tail = unfolded ? NULL : tail_build(W[W_D_UP_W], W[W_D_UP_B], W[W_D_FINAL_W], W[W_D_FINAL_B]);
+    tail_t* tail = unfolded == 1 ? NULL : tail_build(W[W_D_UP_W], W[W_D_UP_B], W[W_D_FINAL_W], W[W_D_FINAL_B]);
     const int64_t ntiles = (B + LT - 1) / LT;
     int err = 0;
     if (nthreads < 1) nthreads = 1;

@@ -111,3 +111,15 @@ def test_nan_policy_is_propagation(oracle):
     leaves[1, 100] = np.nan
     got = oracle.encode(leaves)
     assert np.array_equal(got[0], clean[0]) and np.array_equal(got[2], clean[2])
+
+
+def test_folded_tail_without_the_rows_outside_a_voxels_reach_is_bit_identical(oracle, golden):
+    """The GPU's full-chunk tail (tail_rows16_k, round 5) never runs the W-rows (pd, ph) whose composite weights are structurally zero
+    for a tile; the oracle's tail_apply multiplies them.  Restated on the CPU (tail_skip_rows): identical bits on the golden indices,
+    on random indices, and on the pre-activations (debug slot) — the skipped chains are fmaf(0, x, .) = +0 and acc + (+0) = acc."""
+    rng = np.random.default_rng(11)
+    idx = np.concatenate([golden["idx_rand"][:96], golden["idx_edge"], rng.integers(0, 256, size=(160, 64), dtype=np.uint8)])
+    a, da = oracle.decode(idx, threads=8, debug=("d_pre",))
+    b, db = oracle.decode(idx, threads=8, debug=("d_pre",), tail_skip_rows=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(da["d_pre"].view(np.uint32), db["d_pre"].view(np.uint32))
