@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma32_k(ConvArgs A, const in
     for (int po = g0; po < g1; ++po) {
         f32x16 acc[NMT];
         // OUTMODE 2 (folded tail): ROW-BLOCKED accumulation — the four input positions of a W-row (e.x = 4r .. 4r+3) are one fmaf
-        // chain from zero, the row sums are added in row order (oracle tail_apply).  One chain over all 3072-4096 terms was 12x less
+        // chain from zero, the row sums are added in row order (oracle tail_apply_ex).  One chain over all 3072-4096 terms was 12x less
         // accurate on a trained checkpoint (pre-activations of +-20), tests/test_golden_regimes.py.
         f32x16 tot[OUTMODE == 2 ? NMT : 1];
 #pragma unroll

@@ -13,7 +13,7 @@
 //   296 tile-rows x 64 MFMAs per 16 leaves = 1 212 416 MAC/leaf issued (exact D x H would be 288 tile-rows = 1 179 648: the four corner
 //   cells (od,oh) in {0,7}^2 have boxes no other cell shares; W cannot be skipped with all 8 ow of a cell in one tile).
 //
-// Arithmetic = the oracle's tail_apply, unchanged: per voxel the input rows of its planes ascending, the four positions of a W-row one
+// Arithmetic = the oracle's tail_apply_ex (its skip_rows = 1 form restates this kernel; both forms give the same bits): per voxel the input rows of its planes ascending, the four positions of a W-row one
 // fmaf chain from zero (channels in P8 order), row sums added in row order.  A row outside the voxel's reach in H has all-zero
 // composite weights there: its chain is fmaf(0, x, .) = +0 for the finite activations a decoder produces, and tot + (+0) = tot
 // (tot is never -0: it starts at +0 and x + (-x) = +0), so not running the row is bit-identical to running it.
