@@ -67,7 +67,7 @@ class HipBackend final : public IVQVAECodec {
 		if (std::holds_alternative<std::filesystem::path>(config.source)) {
 			rc = vqhip_create(std::get<std::filesystem::path>(config.source).string().c_str(), nullptr, 0, deviceId(), &codec_);
 		} else if (std::holds_alternative<EmbeddedModel>(config.source)) {
-			// embedded weight pack: the build may define g_vqhip_pack_data/g_vqhip_pack_size
+			// embedded weight pack: see the build modes at the end of this header
 			rc = vqhip_create(nullptr, embeddedData(), embeddedSize(), deviceId(), &codec_);
 		} else {
 			throw std::logic_error("Unsupported model source type.");
@@ -95,12 +95,27 @@ class HipBackend final : public IVQVAECodec {
 	std::vector<int64_t> latentShape_;
 };
 
-#ifndef VQVDB_HIP_EMBEDDED_PACK
-inline const void* HipBackend::embeddedData() { return nullptr; }
-inline size_t HipBackend::embeddedSize() { return 0; }
-#else
+// Embedded weight pack — CodecConfig::source = EmbeddedModel{}, the value both SOPs hard-code (SOP_VQVDB_Encoder.cpp:63-67,
+// SOP_VQVDB_Decoder.cpp:58-62).  The role bin/bin_model.h plays for TorchBackend.cpp:20,39-43.  Three build modes:
+//   -DVQVDB_HIP_EMBEDDED_PACK_HEADER='"bin/vqhip_pack.h"'   the adapter includes the generated header itself (one TU: the factory).
+//        Works with `python -m vqvdb_amd.weightpack --header m.vqw vqhip_pack.h` AND with the reference's own
+//        `python/convert_to_header.py m.vqw vqhip_pack.h --name g_vqhip_pack_data` (whose size object is called
+//        g_vqhip_pack_data_size: the size is taken from the array type, which both tools complete).
+//   -DVQVDB_HIP_EMBEDDED_PACK                                the two objects are linked in from a TU of their own
+//        (`gcc -x c -c vqhip_pack.h`, output of vqvdb_amd.weightpack --header: external linkage, extern "C").
+//   neither                                                   EmbeddedModel is refused with a message (no weights in this build).
+#if defined(VQVDB_HIP_EMBEDDED_PACK_HEADER)
+#include VQVDB_HIP_EMBEDDED_PACK_HEADER
+inline const void* HipBackend::embeddedData() { return g_vqhip_pack_data; }
+inline size_t HipBackend::embeddedSize() { return sizeof(g_vqhip_pack_data); }
+#elif defined(VQVDB_HIP_EMBEDDED_PACK)
+extern "C" {
 extern const unsigned char g_vqhip_pack_data[];
 extern const size_t g_vqhip_pack_size;
+}
 inline const void* HipBackend::embeddedData() { return g_vqhip_pack_data; }
 inline size_t HipBackend::embeddedSize() { return g_vqhip_pack_size; }
+#else
+inline const void* HipBackend::embeddedData() { return nullptr; }
+inline size_t HipBackend::embeddedSize() { return 0; }
 #endif

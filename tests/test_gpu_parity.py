@@ -183,6 +183,38 @@ def test_cpp_adapter_orchestrator_roundtrip(codec, pack, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_embedded_model_harness_matches_path_source(codec, pack, tmp_path):
+    """CodecConfig::source = EmbeddedModel{} (both reference SOPs: SOP_VQVDB_Encoder.cpp:63-67, SOP_VQVDB_Decoder.cpp:58-62):
+    leaf_harness_embedded (the weight pack compiled in with `python -m vqvdb_amd.weightpack --header`) round-trips
+    5 000 leaves through HipBackend and gives the bytes of the path-source build and of the C-ABI path."""
+    import subprocess
+    from vqvdb_amd.build import build_default_embedded_harness, build_harness
+    emb, plain = build_default_embedded_harness(), build_harness()
+    assert pack == weightpack.dumps(synth.make_weights(0)), "the embedded harness carries the seed-0 pack"
+    leaves = synth.make_leaves(5000, seed=77)
+    (tmp_path / "m.vqw").write_bytes(pack)
+    leaves.tofile(tmp_path / "in.f32")
+    want_idx = codec.encode(leaves)
+    want_rec = codec.decode(want_idx)
+    files = {}
+    for tag, exe, src in (("emb", emb, "@embedded"), ("path", plain, str(tmp_path / "m.vqw"))):
+        for batch in (64, 2048):
+            r = subprocess.run([exe, "compress", src, str(tmp_path / "in.f32"), str(tmp_path / f"{tag}.vqvdb"), str(batch)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            files[tag, batch] = (tmp_path / f"{tag}.vqvdb").read_bytes()
+            r = subprocess.run([exe, "decompress", src, str(tmp_path / f"{tag}.vqvdb"), str(tmp_path / f"{tag}.f32"), str(batch)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            got = np.fromfile(tmp_path / f"{tag}.f32", dtype=np.float32).reshape(5000, 512)
+            assert np.array_equal(_bits(got), _bits(want_rec)), (tag, batch)
+    assert len(set(files.values())) == 1
+    body = np.frombuffer(files["emb", 64][-5000 * 76:], dtype=np.uint8).reshape(5000, 76)
+    assert np.array_equal(body[:, 12:], want_idx)
+    r = subprocess.run([emb, "errors", "@embedded"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([plain, "errors", "@embedded"], capture_output=True, text=True)       # no pack in that build: refused, loudly
+    assert r.returncode == 1 and "no weight pack given" in r.stderr
+
+
 def _origins(n, start=0):
     i = np.arange(start, start + n, dtype=np.int64)
     return np.stack([8 * (i % 1024), 8 * ((i // 1024) % 1024), 8 * (i // 1048576)], axis=1).astype(np.int32)

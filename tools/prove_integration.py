@@ -12,6 +12,16 @@ Checks:
   3. BackendType::LibTorch / ::ONNX keep their numeric values (0, 1) and HIP is 2;
   4. create(cfg, BackendType::ONNX) in this build (ONNX disabled) still takes the reference's default branch -> nullptr.
 
+  5. INTEGRATION.md §3 (the SOP diff): the one-line change `BackendType::ONNX` -> `BackendType::HIP` is applied to temporary copies of
+     the reference's real src/SOP/SOP_VQVDB_Encoder.cpp and SOP_VQVDB_Decoder.cpp (anchors asserted), the statements of their
+     initializeCodec() from `CodecConfig config;` to the `create(...)` call are lifted VERBATIM out of the patched text into a test
+     function (the SOP files themselves need the Houdini SDK and cannot be compiled here), and compiled against the patched real
+     factory with a weight pack embedded in each documented way: this repository's generator
+     (`python -m vqvdb_amd.weightpack --header`, header mode and object mode) and the reference's own python/convert_to_header.py
+     with `--name g_vqhip_pack_data`.  On this GPU-less box `create({CUDA, EmbeddedModel{}}, HIP)` must fail at the DEVICE
+     ("no HIP device available"), i.e. after the embedded pack was found and parsed — never with "no weight pack given";
+     a build without an embedded pack must fail with exactly that message.
+
     python tools/prove_integration.py        -> exit code 0 and "integration proof: OK"
 """
 import os
@@ -59,6 +69,89 @@ def patch_sources(src_dir: str) -> None:
     open(cpp, "w").write(c)
 
 
+SOP_FILES = ("SOP_VQVDB_Encoder.cpp", "SOP_VQVDB_Decoder.cpp")
+SOP_OLD = "IVQVAECodec::create(config, BackendType::ONNX);"
+SOP_NEW = "IVQVAECodec::create(config, BackendType::HIP);"
+
+
+def sop_init_statements() -> list:
+    """INTEGRATION.md §3 applied to the text of the two SOPs; returns, per SOP, the statements from `CodecConfig config;`
+    through the patched create() call — what the SOP will execute to get its backend."""
+    out = []
+    for f in SOP_FILES:
+        t = open(os.path.join("/root/reference/src/SOP", f)).read()
+        assert t.count(SOP_OLD) == 1, f"INTEGRATION.md §3 anchor not found exactly once in {f}"
+        t = t.replace(SOP_OLD, SOP_NEW)
+        a = t.index("CodecConfig config;")
+        b = t.index(SOP_NEW) + len(SOP_NEW)
+        block = t[a:b]
+        assert "config.source = EmbeddedModel{};" in block and "config.device = CodecConfig::Device::CUDA;" in block, f"{f}: SOP no longer hard-codes CUDA + EmbeddedModel"
+        out.append((f, block))
+    return out
+
+
+SOP_MAIN = r'''
+#include <cstdio>
+#include <memory>
+#include "core/IVQVAECodec.hpp"
+%s
+int main() {
+	const bool a = sop_0(), b = sop_1();
+	std::printf("sop_encoder_backend=%%s sop_decoder_backend=%%s\n", a ? "object" : "nullptr", b ? "object" : "nullptr");
+	return 0;
+}
+'''
+
+
+def prove_sop_embedded(tmp: str, src: str, lib: str, env: dict) -> bool:
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from vqvdb_amd import weightpack
+    pack = weightpack.dumps({"encoder.pre.0.bias": np.arange(16, dtype=np.float32)})   # parses; the device check comes before the shape validation
+    fns = "".join("static bool sop_%d() {\n\t// %s, INTEGRATION.md §3 applied\n\t%s\n\treturn backend != nullptr;\n}\n" % (i, f, block)
+                  for i, (f, block) in enumerate(sop_init_statements()))
+    open(os.path.join(tmp, "sop_main.cpp"), "w").write(SOP_MAIN % fns)
+    vqw = os.path.join(tmp, "model.vqw")
+    open(vqw, "wb").write(pack)
+    own = os.path.join(tmp, "own")
+    ref = os.path.join(tmp, "ref")
+    os.makedirs(os.path.join(own, "bin"))
+    os.makedirs(os.path.join(ref, "bin"))
+    r = subprocess.run([sys.executable, "-m", "vqvdb_amd.weightpack", "--header", vqw, os.path.join(own, "bin", "vqhip_pack.h")], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([sys.executable, "/root/reference/python/convert_to_header.py", vqw, os.path.join(ref, "bin", "vqhip_pack.h"), "--name", "g_vqhip_pack_data"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    obj = os.path.join(tmp, "vqhip_pack.o")
+    subprocess.run(["gcc", "-x", "c", "-c", os.path.join(own, "bin", "vqhip_pack.h"), "-o", obj], check=True)
+    base = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-DENABLE_HIP_BACKEND", "-I", src, "-I", os.path.join(src, "core"),
+            os.path.join(src, "core", "IVQVAECodec.cpp"), os.path.join(tmp, "sop_main.cpp")]
+    link = ["-L" + os.path.dirname(lib), "-lvqvdb_hip", "-Wl,-rpath," + os.path.dirname(lib)]
+    builds = [("weightpack --header, included by the adapter", ['-DVQVDB_HIP_EMBEDDED_PACK_HEADER="bin/vqhip_pack.h"', "-I", own], True),
+              ("weightpack --header, linked as its own object", ["-DVQVDB_HIP_EMBEDDED_PACK", obj], True),
+              ("reference convert_to_header.py --name g_vqhip_pack_data", ['-DVQVDB_HIP_EMBEDDED_PACK_HEADER="bin/vqhip_pack.h"', "-I", ref], True),
+              ("no embedded pack in the build", [], False)]
+    ok = True
+    for name, extra, embedded in builds:
+        exe = os.path.join(tmp, "sop_proof")
+        r = subprocess.run(base + extra + ["-o", exe] + link, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr[-3000:])
+            print(f"  SOP route [{name}]: FAILED to compile/link")
+            ok = False
+            continue
+        r = subprocess.run([exe], capture_output=True, text=True, env=env)
+        msgs = [ln for ln in r.stderr.splitlines() if ln.startswith("Failed to create VQ-VAE backend:")]
+        if embedded:
+            good = (len(msgs) == 2 and all("no HIP device available" in m for m in msgs)) or "backend=object" in r.stdout      # a GPU box would get as far as the shape validation
+            good = good and "no weight pack given" not in r.stderr
+        else:
+            good = len(msgs) == 2 and all("no weight pack given (embedded model absent from this build)" in m for m in msgs)
+        print(f"  SOP route [{name}]: {r.stdout.strip()} | {msgs[0] if msgs else r.stderr.strip()} -> {'ok' if good else 'FAILED'}")
+        ok = ok and good
+    return ok
+
+
 def main() -> int:
     if not os.path.isdir(REF):
         print("integration proof: SKIPPED (no /root/reference here — this script runs in the build container only)")
@@ -98,6 +191,7 @@ def main() -> int:
         print("stderr of the patched reference factory:\n  " + "\n  ".join(r.stderr.strip().splitlines()))
         ok = (r.returncode == 0 and "hip_missing_pack=nullptr onnx_disabled=nullptr hip_cpu_device=nullptr" in r.stdout
               and r.stderr.count("Failed to create VQ-VAE backend:") == 3 and "Model file not found at path: /nonexistent/model.vqw" in r.stderr)
+        ok = prove_sop_embedded(tmp, src, lib, env) and ok
         print("integration proof: " + ("OK" if ok else "FAILED"))
         return 0 if ok else 1
     finally:

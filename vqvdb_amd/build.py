@@ -40,6 +40,7 @@ def build(force: bool = False, report: bool = False) -> str:
                     if key in line and "remark" in line:
                         print(f"{name:110s} {line.split('remark:')[1].split('[-R')[0].strip()}")
     build_harness(force or stale)
+    build_default_embedded_harness(force or stale)
     return LIB
 
 
@@ -59,6 +60,60 @@ def build_harness(force: bool = False) -> str:
             sys.stderr.write(r.stderr)
             raise RuntimeError("g++ failed building leaf_harness")
     return HARNESS
+
+
+def build_harness_embedded(pack: bytes, exe: str, mode: str = "header", ref_tool: str | None = None) -> str:
+    """leaf_harness with a weight pack compiled in, for CodecConfig::source = EmbeddedModel{} (INTEGRATION.md §2a).
+
+    mode "header": the adapter includes the generated header (-DVQVDB_HIP_EMBEDDED_PACK_HEADER);
+    mode "object": the header is compiled as a C translation unit of its own and linked (-DVQVDB_HIP_EMBEDDED_PACK);
+    ref_tool: path of the reference's python/convert_to_header.py — the header is then produced by THAT tool
+    (build container only) to show that its output links too."""
+    import tempfile
+    from . import weightpack
+    tmp = tempfile.mkdtemp(prefix="vqhip_embed_")
+    try:
+        hdr = os.path.join(tmp, "vqhip_pack.h")
+        if ref_tool:
+            vqw = os.path.join(tmp, "model.vqw")
+            with open(vqw, "wb") as f:
+                f.write(pack)
+            subprocess.run([sys.executable, ref_tool, vqw, hdr, "--name", weightpack.HEADER_SYMBOL], check=True, capture_output=True)
+        else:
+            with open(hdr, "w") as f:
+                f.write(weightpack.to_header(pack, "embedded.vqw"))
+        srcs = [os.path.join(HERE, "host", f) for f in ("leaf_harness.cpp", "codec_factory.cpp")]
+        cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-o", exe, *srcs]
+        if mode == "header":
+            cmd += ["-DVQVDB_HIP_EMBEDDED_PACK_HEADER=\"vqhip_pack.h\"", "-I", tmp]
+        else:
+            obj = os.path.join(tmp, "vqhip_pack.o")
+            subprocess.run(["gcc", "-x", "c", "-c", hdr, "-o", obj], check=True, capture_output=True)
+            cmd += ["-DVQVDB_HIP_EMBEDDED_PACK", obj]
+        cmd += ["-L" + HERE, "-lvqvdb_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-4000:])
+            raise RuntimeError("g++ failed building the embedded-pack leaf_harness")
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return exe
+
+
+HARNESS_EMBEDDED = os.path.join(HERE, "host", "leaf_harness_embedded")
+
+
+def build_default_embedded_harness(force: bool = False) -> str:
+    """host/leaf_harness_embedded: the harness with the synthetic seed-0 weight pack compiled in (object mode), so the
+    EmbeddedModel route — the one both reference SOPs take — is a built artefact that the CPU and GPU tests run."""
+    deps = [os.path.join(HERE, "host", f) for f in ("leaf_harness.cpp", "codec_factory.cpp", "vqvdb_stream.hpp", "codec_interface.hpp")] + [
+        os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip_backend.hpp"), os.path.join(os.path.dirname(HERE), "include", "vqvdb_hip.h"),
+        os.path.join(HERE, "weightpack.py"), os.path.join(HERE, "synth.py"), LIB]
+    if force or not os.path.exists(HARNESS_EMBEDDED) or any(os.path.getmtime(d) > os.path.getmtime(HARNESS_EMBEDDED) for d in deps):
+        from . import synth, weightpack
+        build_harness_embedded(weightpack.dumps(synth.make_weights(0)), HARNESS_EMBEDDED, "object")
+    return HARNESS_EMBEDDED
 
 
 if __name__ == "__main__":

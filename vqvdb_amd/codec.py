@@ -44,6 +44,9 @@ class EmbeddedModel:            # IVQVAECodec.hpp:27
     pass
 
 
+EMBEDDED_PACK_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "embedded_model.vqw")
+
+
 @dataclass
 class TensorView:               # IVQVAECodec.hpp:49-53 — non-owning view of host data
     data: np.ndarray
@@ -582,9 +585,13 @@ class HipBackend(IVQVAECodec):
     def __init__(self, config: CodecConfig):
         if config.device != CodecConfig.Device.CUDA:
             raise RuntimeError("HIP backend requires Device::CUDA (GPU); there is no CPU path in this backend")
-        if isinstance(config.source, EmbeddedModel):
-            raise RuntimeError("no embedded weight pack in this build: pass a VQWPACK1 path or bytes as source")
-        self._codec = HipCodec(config.source, config.device_id)
+        source = config.source
+        if isinstance(source, EmbeddedModel):
+            # the Python side's bin_model.h: a pack installed beside the package (the C++ adapter compiles one in)
+            source = os.environ.get("VQVDB_HIP_EMBEDDED_PACK_FILE", EMBEDDED_PACK_FILE)
+            if not os.path.exists(source):
+                raise RuntimeError("vqhip_create: no weight pack given (embedded model absent from this build)")
+        self._codec = HipCodec(source, config.device_id)
         self._latent = self._codec.latent_shape()
 
     def encode(self, leafBatch: TensorView) -> Tensor:

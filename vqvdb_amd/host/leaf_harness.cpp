@@ -11,6 +11,7 @@
 //   leaf_harness loopbench  <pack> <n_leaves> <tmp.vqvdb> <batch>[,<batch>...] [threads]   (both loops, timed per phase, synthetic leaves;
 //                           threads: pack loop and leaf copies on that many threads, 0 = half the cores, like the reference's tbb::parallel_for)
 //   leaf_harness errors     <pack>
+//   <pack> = @embedded selects CodecConfig::source = EmbeddedModel{} (builds with -DVQVDB_HIP_EMBEDDED_PACK[_HEADER])
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
 //   leaf_harness readcheck  <ref_writer_v3.vqvdb> <batch>   (no GPU needed: StreamReader over the file the reference's writer wrote)
 //   leaf_harness makefile   <out.vqvdb> <n_leaves> (synthetic indices; config-3 input)
@@ -49,7 +50,10 @@ vqvdb::Coord3i originOf(size_t i) {  // synthetic leaf origins on the 8-voxel la
 std::unique_ptr<IVQVAECodec> makeBackend(const std::string& pack) {
 	CodecConfig cfg;
 	cfg.device = CodecConfig::Device::CUDA;
-	cfg.source = std::filesystem::path(pack);
+	if (pack == "@embedded")
+		cfg.source = EmbeddedModel{};  // what both SOPs pass (SOP_VQVDB_Encoder.cpp:63-67); needs a build with an embedded pack
+	else
+		cfg.source = std::filesystem::path(pack);
 	auto be = IVQVAECodec::create(cfg, BackendType::HIP);
 	if (!be) throw std::runtime_error("VQVAECodec: Backend cannot be null.");  // VQVAECodec.cpp:71-75
 	return be;

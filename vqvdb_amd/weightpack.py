@@ -85,3 +85,53 @@ def from_state_dict(state_dict) -> dict[str, np.ndarray]:
         a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
         out[k] = a.astype(np.float32)
     return out
+
+
+# --- C header embedder (role of python/convert_to_header.py:4-44 + src/Bin/bin_model.h) -------------------------------
+HEADER_SYMBOL = "g_vqhip_pack_data"      # include/vqvdb_hip_backend.hpp reads g_vqhip_pack_data / g_vqhip_pack_size
+
+
+def to_header(pack: bytes, source_name: str = "model.vqw") -> str:
+    """C/C++ text that embeds a weight pack for ``CodecConfig.source = EmbeddedModel{}``.
+
+    The output is valid as a header (``-DVQVDB_HIP_EMBEDDED_PACK_HEADER='"bin/vqhip_pack.h"'``: the adapter includes it, the way
+    TorchBackend.cpp:20 includes bin/bin_model.h) and as a translation unit of its own (``gcc -x c -c vqhip_pack.h`` next to
+    ``-DVQVDB_HIP_EMBEDDED_PACK``).  In C++17 the two objects are ``inline const`` (external linkage, one copy however many
+    translation units include the header); in C and older C++ they are declared ``extern`` first so that the ``const`` definitions
+    keep external linkage; 12 bytes per line like the reference tool.  Define VQHIP_PACK_DECLARE_ONLY to get the declarations alone."""
+    loads(pack)                                     # refuses anything that is not a VQWPACK1 pack
+    n = len(pack)
+    rows = [", ".join(f"0x{b:02x}" for b in pack[i:i + 12]) for i in range(0, n, 12)]
+    return (
+        "#ifndef VQHIP_PACK_H_INCLUDED\n#define VQHIP_PACK_H_INCLUDED\n\n#include <stddef.h>\n\n"
+        f"/* Weight pack: {source_name}\n * Size:        {n} bytes (VQWPACK1, vqvdb_amd/weightpack.py) */\n\n"
+        "#if defined(__cplusplus) && __cplusplus >= 201703L\n"
+        "#define VQHIP_PACK_OBJECT inline const /* C++17 inline variable: external linkage, ONE copy however many TUs include this */\n"
+        "#else\n#define VQHIP_PACK_OBJECT const\n#endif\n"
+        "#ifdef __cplusplus\nextern \"C\" {\n#endif\n"
+        "#ifdef VQHIP_PACK_DECLARE_ONLY\n"
+        f"extern const unsigned char {HEADER_SYMBOL}[{n}];\nextern const size_t g_vqhip_pack_size;\n"
+        "#else\n"
+        "#if !(defined(__cplusplus) && __cplusplus >= 201703L)\n"
+        f"extern const unsigned char {HEADER_SYMBOL}[{n}]; /* declared extern first: the const definitions keep external linkage */\n"
+        "extern const size_t g_vqhip_pack_size;\n#endif\n"
+        f"VQHIP_PACK_OBJECT size_t g_vqhip_pack_size = {n};\n"
+        f"VQHIP_PACK_OBJECT unsigned char {HEADER_SYMBOL}[{n}] = {{\n    " + ",\n    ".join(rows) + "\n};\n"
+        "#endif\n#ifdef __cplusplus\n}\n#endif\n#undef VQHIP_PACK_OBJECT\n\n#endif /* VQHIP_PACK_H_INCLUDED */\n")
+
+
+def save_header(pack_path, header_path) -> int:
+    import os
+    with open(pack_path, "rb") as f:
+        pack = f.read()
+    with open(header_path, "w") as f:
+        f.write(to_header(pack, os.path.basename(str(pack_path))))
+    return len(pack)
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="VQWPACK1 tools: --header embeds a weight pack into a C/C++ header for EmbeddedModel builds")
+    ap.add_argument("--header", nargs=2, metavar=("MODEL.vqw", "OUT.h"), required=True)
+    a = ap.parse_args()
+    print(f"{a.header[1]}: {save_header(*a.header)} bytes as {HEADER_SYMBOL}[] / g_vqhip_pack_size")
