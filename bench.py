@@ -136,7 +136,7 @@ def hbm_traffic(kernel):
 # bytes per leaf a layer reads + writes when every tensor crosses HBM exactly once (fp32, leaf-tile layout): input (+ residual input) + output
 LAYER_IO_BYTES = {"pack_leaves": 2048 + 3072, "enc_conv_first_stats": 3072, "enc_conv_first_gn": 3072 + 32768, "enc_res16_conv1": 2 * 32768, "enc_res16_conv2": 3 * 32768,
                   "enc_down": 32768 + 8192, "enc_res32_conv1": 2 * 8192, "enc_res32_conv2": 3 * 8192, "enc_vq": 8192 + 64,
-                  "dec_stem_gn": 64 + 16384, "dec_res64_conv1": 2 * 16384, "dec_res64_conv2": 3 * 16384, "dec_tail": 16384 + 2048}
+                  "dec_stem_gn": 64 + 16384, "dec_res64_conv1": 2 * 16384, "dec_res64_conv2": 3 * 16384, "dec_tail": 16384 + 2048, "dec_tail_slab": 16384 + 2048, "dec_tail_rows32": 16384 + 2048, "dec_tail_groups": 16384 + 2048}
 ALGORITHMIC_BYTES = 2048 + 64      # per leaf, either direction: the leaf and its 64 indices
 
 
@@ -156,7 +156,8 @@ def path_traffic(kernels):
 # FLOPs per leaf a kernel issues that the RESULT does not need (they are inside issued_flop_per_leaf): the first conv is run twice
 # (statistics pass, then recompute + normalise + store: the first pass's MACs buy no output), and the folded decoder tail multiplies the
 # structural zeros its 16-voxel tiles cannot skip (884 736 MAC/leaf are structurally non-zero; the corner tiles and the W axis are issued in full)
-NOT_USEFUL_FLOP = {"enc_conv_first_stats": None, "dec_tail": lambda issued: issued - 2.0 * 884736, "dec_tail_slab": lambda issued: issued - 2.0 * 884736}
+NOT_USEFUL_FLOP = {"enc_conv_first_stats": None, "dec_tail": lambda issued: issued - 2.0 * 884736, "dec_tail_slab": lambda issued: issued - 2.0 * 884736,
+                   "dec_tail_rows32": lambda issued: issued - 2.0 * 884736, "dec_tail_groups": lambda issued: issued - 2.0 * 884736}
 
 
 def useful_flop_per_leaf(kernels):
@@ -341,6 +342,8 @@ def main():
                                          gpu_numa_nodes=nodes if len(nodes) == local_world and None not in nodes else None)
         except Exception as e:  # noqa: BLE001 — binding is an optimisation, never a reason to fail
             affinity = {"error": f"{type(e).__name__}: {e}"}
+    elif world > 1 and cpu_rehearsal:      # the CPU protocol rehearsal binds too (no PCI topology: the even split), so the plan itself is exercised
+        affinity = bind_rank_to_cpus(local, local_world)
     if dist:
         if rehearsal:
             torch.distributed.init_process_group("gloo")
@@ -356,7 +359,8 @@ def main():
         torch.distributed.all_reduce(one)
         ranks_seen = int(one.item())
         objs = [None] * torch.distributed.get_world_size()
-        torch.distributed.all_gather_object(objs, {"rank": rank, "local_rank": local, "device": dev_index, "name": dev_name,
+        torch.distributed.all_gather_object(objs, {"rank": rank, "local_rank": local, "device": dev_index, "device_by_local_rank": local, "name": dev_name,
+                                                   "cpu_set": sorted(os.sched_getaffinity(0)) if affinity and affinity.get("bound") else None,
                                                    "pci_bus_id": getattr(dev_props, "pci_bus_id", None),
                                                    "cpus": (affinity or {}).get("cpus_bound")})
         devices_seen = objs
@@ -514,12 +518,23 @@ def main():
             host = {"skipped": "host-memory legs run at N = 1 only (one process per GPU already saturates its PCIe link)"}
         enc_roof, dec_roof = roofline_of(ek, ENC_FLOP, enc_lps / world), roofline_of(dk, DEC_FLOP, dec_lps / world)
         dtail = next((k for k in dk if k["kernel"].startswith("dec_tail")), None)
+        # the decode half of the metric inside `roofline` too (the object a summariser keeps whole): BASELINE's metric is
+        # "encode+quantize AND decode"; `value` is the encode leg, these are the decode leg of the same run
+        enc_roof.update({
+            "decode_value": round(dec_lps, 1), "decode_unit": "leaves/s", "decode_ms_per_step": round(t_dec / steps * 1e3, 4),
+            "decode_kernel": dec_roof["kernel"], "decode_frac": dec_roof["frac"], "decode_achieved": dec_roof["achieved"],
+            "decode_avg_launch_ms": dec_roof["avg_launch_ms"],
+            "decode_whole_path_frac": dec_roof["whole_path_frac"], "decode_whole_path_frac_useful": dec_roof["whole_path_frac_useful"],
+            "dec_tail_ms": dtail["avg_ms"] if dtail else None,
+            "decode_traffic_bytes": dec_roof["whole_path_traffic_bytes"], "decode_traffic_stale": dec_roof["traffic_stale"],
+            "decode_workload": "decode of the same 65536-leaf index batches, resident in HBM, timed like `value` (K steps, barrier + synchronize on both sides)",
+        })
         out = {
             "metric": "8^3 leaves/s encode+quantize (decode reported under 'decode')",
             "value": round(enc_lps, 1), "unit": "leaves/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(t_enc / steps * 1e3, 4), "timed_region_s": round(t_enc, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not cpu_rehearsal else "REHEARSAL on CPU with a stand-in codec: protocol test only, not a measurement",
-            "config": {"workload": (f"BASELINE configs[1]: 1xMI355X, 1M synthetic leaves (16 x 65536-leaf batches, cycled for {steps} steps), fp32 encoder+quantizer, K=256 D=128" if world == 1 else
+            "config": {"workload": (f"BASELINE configs[1]: 1xMI355X, 1M synthetic leaves (16 x 65536-leaf batches, cycled for {steps} steps), fp32 encoder+quantizer, K=256 D=128; decode leg: the same batches' indices -> voxels, same K steps (roofline.decode_*)" if world == 1 else
                                     f"BASELINE configs[3]: {world}xMI355X encode, leaves sharded across GPUs, {steps * BATCH} leaves per GPU "
                                     f"(>= the 8 Mi-leaf shard of the 64M-leaf job; 65536-leaf batches), fp32 encoder+quantizer, K=256 D=128"),
                        "leaves_per_step_per_gpu": BATCH, "leaves_per_gpu": steps * BATCH, "steps_requested": args.steps,

@@ -17,7 +17,11 @@
  * through the leaf that holds them exactly as in the reference's fp32 graph, and what that leaf encodes to is unspecified (some
  * valid uint8 per position; torch.argmin of a NaN row is unspecified too).  Every OTHER leaf of the batch is unaffected bit for bit
  * (no arithmetic mixes leaves; tests/test_gpu_parity.py::test_nan_inf_poison_stays_inside_its_own_leaf), and decode, whose input is
- * indices, always returns finite voxels.
+ * indices, always returns finite voxels.  (Inside decode, should an activation overflow to Inf / NaN — possible only with weights
+ * far outside any trained range — the full-chunk folded tail (tail_rows16_k) does not multiply the composite weights that are
+ * structurally zero, so voxels outside the poisoned activation's reach stay finite, as in the reference's unfolded conv chain;
+ * the slab kernel (VQHIP_TAIL=slab) and the oracle's skip_rows = 0 form compute 0 x Inf = NaN there.  For finite activations all
+ * forms are bit-identical; tests/test_gpu_parity.py::test_large_path_kernel_variants_agree pins that.)
  *
  * Every function returns VQHIP_OK (0) or a negative status; the message is available from
  * vqhip_last_error().  Nothing throws, nothing aborts.  A codec handle owns its device

@@ -121,3 +121,33 @@ def test_bench_plain_command_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--bogus-flag"],
                          capture_output=True, text=True, env=env, timeout=600)
     assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_eight_rank_rehearsal_matches_what_the_first_8_gpu_run_must_print():
+    """`bench.py --gpus 8` as the driver launches it, eight gloo ranks with the CPU stand-in codec: ranks_seen == 8, eight distinct
+    LOCAL_RANK -> device bindings, the ranks' CPU sets are a partition of this box's allowed cores (or no binding at all when there are
+    fewer cores than ranks), every rank covers its configs[3] shard (128 batches = 8 Mi leaves), and the JSON stays ONE line below 64 KB."""
+    import json
+    import subprocess
+    env = dict(os.environ, VQ_BENCH_CPU_REHEARSAL="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 65536, (len(lines), len(lines[0]) if lines else 0)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["n_devices_seen"] == 8 and d["scaling"] == "weak"
+    assert d["steps"] == 128 and d["config"]["leaves_per_gpu"] == 8 * 1024 * 1024 and "configs[3]: 8xMI355X" in d["config"]["workload"]
+    seen = d["devices_seen"]
+    assert [o["rank"] for o in seen] == list(range(8)) and sorted(o["device_by_local_rank"] for o in seen) == list(range(8))
+    allowed = sorted(os.sched_getaffinity(0))
+    sets = [o["cpu_set"] for o in seen]
+    if len(allowed) >= 8:
+        assert all(sets) and sorted(sum(sets, [])) == allowed[:len(allowed) // 8 * 8] and len({tuple(x) for x in sets}) == 8
+    else:
+        assert not any(sets)
+    assert len(d["per_rank"]["encode_leaves_per_s"]) == 8
+    assert 0 < d["value"] <= sum(d["per_rank"]["encode_leaves_per_s"]) * 1.001
+    assert abs(d["ms_per_step"] * d["steps"] * 1e-3 * d["value"] - 8 * 128 * 65536) < 1e-3 * 8 * 128 * 65536
+    assert d["roofline"]["decode_value"] > 0 and d["roofline"]["decode_kernel"]

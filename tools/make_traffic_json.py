@@ -35,7 +35,7 @@ LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the lib
     (r"gn_relu_stats_k<64", "dec_gn_relu_stats"), (r"stem_fused_k", "dec_stem_gn"), (r"stem_taps_k", "dec_stem_gn"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, false, 8, false, false[,>]", "dec_res64_conv1"),
     (r"conv_rows16_k<64, 64, 4, 4, 3, 1, 1, 1, true, 0, true, false[,>]", "dec_res64_conv2"),
-    (r"tail_rows16_k<", "dec_tail"), (r"conv_mfma32_k<64, 128, 64, 4, 8,", "dec_tail_slab"),
+    (r"tail_rows16_k<", "dec_tail"), (r"tail_rows32_k<", "dec_tail_rows32"), (r"tail_groups16_k<", "dec_tail_groups"), (r"conv_mfma32_k<64, 128, 64, 4, 8,", "dec_tail_slab"),
 ]
 
 

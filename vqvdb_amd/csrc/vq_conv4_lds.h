@@ -29,6 +29,7 @@
 #include "vq_conv8_lds.h"
 
 constexpr size_t LDS_CONV4 = (size_t)4 * 2048 * 16 + (size_t)2 * 4 * 4 * 2 * 64 * 8;   // 131 072 + 32 768 B = all 160 KB
+static_assert(LDS_CONV4 <= 160 * 1024, "gfx950: 160 KB of LDS per workgroup, all of it dynamic here: the kernel must stay free of static __shared__");
 
 // ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads, 32 no MFMAs
 // STG: who stages the planes.  0: every wave two positions, the two waves of a SIMD at different points of the plane.  1: only the four

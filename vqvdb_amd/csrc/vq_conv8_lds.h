@@ -30,6 +30,7 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 constexpr size_t LDS_CONV8 = (size_t)(27 * 64 + 2 * 4096) * 16;   // 155 648 B
+static_assert(LDS_CONV8 <= 160 * 1024, "gfx950: 160 KB of LDS per workgroup, all of it dynamic here: the kernel must stay free of static __shared__");
 
 // ABL: timing-only ablations for tools/ablate/conv8_lds_ablate.hip (0 in the library): 1 no barriers, 2 no epilogue, 4 no plane
 // write / prefetch, 8 no LDS operand reads, 16 no MFMAs

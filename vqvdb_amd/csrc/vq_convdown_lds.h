@@ -24,6 +24,7 @@
 #include "vq_conv8_lds.h"
 
 constexpr size_t LDS_CONVDOWN = (size_t)2 * 4096 * 16 + (size_t)8 * 2 * 2 * 2 * 64 * 8;   // 131 072 + 32 768 B = all 160 KB
+static_assert(LDS_CONVDOWN <= 160 * 1024, "gfx950: 160 KB of LDS per workgroup, all of it dynamic here: the kernel must stay free of static __shared__");
 
 // ABL (tools/ablate only): 1 no barriers, 2 no epilogue, 4 no plane write / prefetch, 8 no LDS B reads, 16 no A-fragment loads
 // NW: 8 waves (a wave holds both 16-cout tiles of its row: 8 accumulators) or 16 (one tile each: four waves per SIMD hide one another's

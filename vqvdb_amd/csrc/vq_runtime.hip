@@ -162,6 +162,8 @@ const std::map<std::string, KernelInfo>& kernel_info()
         // round 5 (tail_rows16_k): 16-voxel tiles of two (od,oh) cells with one reach box: the structural zeros are skipped along D and H,
         // 296 (tile, input row) pairs x 64 MFMAs of 1024 MACs per 16 leaves = 1 212 416 MAC/leaf (exact D x H: 1 179 648; useful 884 736)
         {"dec_tail", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1212416}},
+        {"dec_tail_rows32", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1212416}},   // the same tiles, a whole 32-leaf tile per wave
+        {"dec_tail_groups", {2.0 * (28311552 + 2048 + 442368), 2.0 * 1212416}},   // the same (tile, input row) pairs in three plane groups
     };
     return m;
 }
@@ -683,8 +685,10 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
     }
     // ... and of tail_groups16_k (vq_tail_groups.h): three groups of output planes, 48 KB slices of up to 11 blocks (pair tiles, then the
     // group's single tiles while their planes last)
-    std::vector<float> wgroups((size_t)TG_STREAM_SLICES * (TG_SLICE / 4), 0.0f);
-    {
+    // (built and uploaded only when VQHIP_TAIL=groups selects that kernel: 7.8 MB of host work per weight refresh otherwise spent for nothing)
+    std::vector<float> wgroups;
+    if (c->tail_groups) {
+        wgroups.assign((size_t)TG_STREAM_SLICES * (TG_SLICE / 4), 0.0f);
         size_t t = 0, tile_rows = 0;
         for (int g = 0; g < 3; ++g)
             for (int pd = tg_pd_lo(g); pd <= tg_pd_hi(g); ++pd)
@@ -710,7 +714,7 @@ int build_folded_tail(vqhip_codec* c, const float* Wu, const float* bu, const fl
         if (t != TG_PHASES || tile_rows != TR_TILE_ROWS) return fail(c, VQHIP_ERR_MODEL, "folded tail: group schedule does not match tail_groups16_k");
     }
     int rc;
-    if ((rc = upload(c, "tail.wgroups", wgroups))) return rc;
+    if (c->tail_groups && (rc = upload(c, "tail.wgroups", wgroups))) return rc;
     if ((rc = upload(c, "tail.wrows", wrows))) return rc;
     if ((rc = upload(c, "tail.w", frags))) return rc;
     if ((rc = upload(c, "tail.b", bias))) return rc;
@@ -1480,8 +1484,8 @@ int decode_chunk(vqhip_codec* c, const uint8_t* d_idx, int64_t n, float* d_out, 
             A.wfrag = w["tail.wrows"], A.bias_frag = w["tail.braw"];
             if (c->tail_groups) {
                 A.wfrag = w["tail.wgroups"];
-                L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_groups16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_GROUPS, s, A); });
-            } else if (c->tail_rows32) L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows32_k<0>, dim3((nt + 3) / 4), dim3(256), LDS_TAIL_ROWS, s, A); });
+                L.run("dec_tail_groups", [&] { hipLaunchKernelGGL(tail_groups16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_GROUPS, s, A); });
+            } else if (c->tail_rows32) L.run("dec_tail_rows32", [&] { hipLaunchKernelGGL(tail_rows32_k<0>, dim3((nt + 3) / 4), dim3(256), LDS_TAIL_ROWS, s, A); });
             else L.run("dec_tail", [&] { hipLaunchKernelGGL(tail_rows16_k<0>, dim3((2 * nt + 7) / 8), dim3(512), LDS_TAIL_ROWS, s, A); });
         } else {
             L.run("dec_tail_slab", [&] { hipLaunchKernelGGL(k_dec_tail, dim3(g8), dim3(512), LDS_DEC_TAIL, s, A, (const int4*)w["steps.tail"]); });
@@ -1822,7 +1826,13 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_FIRST")) c->first_roll = std::strcmp(e, "steps") != 0, c->first_roll_stats = std::strcmp(e, "roll0") == 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
-    if (const char* e = std::getenv("VQHIP_TAIL")) c->tail_rows = std::strcmp(e, "slab") != 0, c->tail_rows32 = std::strcmp(e, "rows32") == 0, c->tail_groups = std::strcmp(e, "groups") == 0;
+    if (const char* e = std::getenv("VQHIP_TAIL")) {
+        if (std::strcmp(e, "rows16") && std::strcmp(e, "slab") && std::strcmp(e, "rows32") && std::strcmp(e, "groups") && *e) {
+            c->err = std::string("VQHIP_TAIL=") + e + ": unknown folded-tail variant (rows16 | rows32 | groups | slab)";
+            return bail(VQHIP_ERR_INVALID);
+        }
+        c->tail_rows = std::strcmp(e, "slab") != 0, c->tail_rows32 = std::strcmp(e, "rows32") == 0, c->tail_groups = std::strcmp(e, "groups") == 0;
+    }
     if (const char* e = std::getenv("VQHIP_R64S")) c->r64s_resident = std::strcmp(e, "stream") != 0;
     if (const char* e = std::getenv("VQHIP_VQ_SPLIT")) c->vq_split = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("VQHIP_TRAIN_STEM")) c->train_stem_lut = std::strcmp(e, "conv") != 0;

@@ -16,6 +16,7 @@
 constexpr int TG_SLOTS = 12;
 constexpr int TG_SLICE = TG_SLOTS * 4096;                            // bytes per weight slice (one phase): up to 11 tile blocks used
 constexpr size_t LDS_TAIL_GROUPS = (size_t)TR_RING * TG_SLICE;       // 144 KB
+static_assert(LDS_TAIL_GROUPS <= 160 * 1024, "gfx950: 160 KB of LDS per workgroup, all of it dynamic here: the kernel must stay free of static __shared__");
 constexpr int TG_PHASES = 160;                                       // (3 + 4 + 3 planes) x 4 rows x 4 positions
 constexpr int TG_STREAM_SLICES = TG_PHASES + 3;                      // the kernel requests slices up to three phases ahead: padding
 constexpr int TG_PIECES = TG_SLICE / 1024 / 8;                       // 1 KB pieces per wave and phase (8 waves)

@@ -60,6 +60,17 @@ constexpr unsigned tr_single_mask(int ph) { return (ph <= 2 ? 1u : 0u) | 2u | (p
 constexpr unsigned tr_mask(bool pair, int ph) { return pair ? tr_pair_mask(ph) : tr_single_mask(ph); }
 constexpr int tr_popc(unsigned m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
 constexpr int tr_nth(unsigned m, int i) { for (int b = 0; b < 32; ++b) if (m >> b & 1) { if (i == 0) return b; --i; } return -1; }
+// A phase's fragment requests run up to two items ahead; in the last phase of a unit they fall on the NEXT unit's slice with the ending unit's mask
+// (the values are discarded and re-requested at the start of run_unit): with at most 7 of the slot's 8 blocks ever addressed they stay inside the slot.
+constexpr int tr_max_blocks()
+{
+    int m = 0;
+    for (int pair = 0; pair < 2; ++pair)
+        for (int ph = 0; ph < 4; ++ph) m = tr_popc(tr_mask(pair != 0, ph)) > m ? tr_popc(tr_mask(pair != 0, ph)) : m;
+    return m;
+}
+static_assert((tr_max_blocks() + 1) * 4096 <= TR_SLICE, "tail_rows16_k: a weight slice's blocks (+1 for the look-ahead across a unit boundary) must fit the ring slot");
+static_assert(LDS_TAIL_ROWS <= 160 * 1024, "gfx950: 160 KB of LDS per workgroup");
 // the two (od,oh) cells of tile `tid` of a unit whose first plane is od0: rows 0-7 of the tile = cell A, rows 8-15 = cell B
 constexpr int tr_cell_a(bool pair, int od0, int tid) { return pair ? od0 * 8 + tid : od0 * 8 + (tid == 3 ? 0 : 2 * tid + 1); }
 constexpr int tr_cell_b(bool pair, int od0, int tid) { return pair ? (od0 + 1) * 8 + tid : od0 * 8 + (tid == 3 ? 7 : 2 * tid + 2); }

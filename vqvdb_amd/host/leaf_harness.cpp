@@ -10,13 +10,17 @@
 //   leaf_harness decompress_stream <pack> <in.vqvdb>   <out.f32>   <batch>   (vqhip_decompress_file)
 //   leaf_harness loopbench  <pack> <n_leaves> <tmp.vqvdb> <batch>[,<batch>...] [threads]   (both loops, timed per phase, synthetic leaves;
 //                           threads: pack loop and leaf copies on that many threads, 0 = half the cores, like the reference's tbb::parallel_for)
+//   leaf_harness loopbench_ptrs <pack> <n_leaves> <tmp.vqvdb> <batch>[,<batch>...]   (the loops on vqhip_encode_leaves / vqhip_decode_leaves over
+//                           scattered 2 KiB heap blocks: INTEGRATION.md §6)
 //   leaf_harness errors     <pack>
+//   leaf_harness threads    <pack> <iterations>  (two HipBackend objects driven from two caller threads + create/destroy churn)
 //   <pack> = @embedded selects CodecConfig::source = EmbeddedModel{} (builds with -DVQVDB_HIP_EMBEDDED_PACK[_HEADER])
 //   leaf_harness streamtest <tmp.vqvdb>          (no GPU needed)
 //   leaf_harness readcheck  <ref_writer_v3.vqvdb> <batch>   (no GPU needed: StreamReader over the file the reference's writer wrote)
 //   leaf_harness makefile   <out.vqvdb> <n_leaves> (synthetic indices; config-3 input)
 #define VQVDB_HIP_STANDALONE
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -479,6 +483,103 @@ int loopbench(const std::string& pack, size_t total, const std::string& tmp, con
 	return 0;
 }
 
+// The same two loops with the leaf-pointer entry points of the C ABI: no pack buffer, no owning Tensor,
+// no per-leaf copies on the caller's side — the loop hands over leaf.buffer().data() pointers (VQVAECodec.cpp:36-59,182-192 replaced).
+// Leaves live the way an OpenVDB tree keeps them: one heap block of 2 KiB per leaf, visited in an order unrelated to the allocation order.
+int loopbenchPtrs(const std::string& pack, size_t total, const std::string& tmp, const std::string& batches) {
+	constexpr size_t BASE = 65536;
+	std::vector<float> base(std::min(total, BASE) * LEAF_VOXELS);
+	uint32_t x = 2463534242u;
+	for (float& v : base) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = static_cast<float>(x >> 8) * (1.0f / 16777216.0f); }
+	const size_t nbase = base.size() / LEAF_VOXELS;
+	std::vector<std::unique_ptr<float[]>> blocks(total);
+	for (auto& b : blocks) b.reset(new float[LEAF_VOXELS]);
+	std::vector<float*> leafOf(total);
+	for (size_t i = 0; i < total; ++i) leafOf[i] = blocks[i].get();
+	for (size_t i = total; i > 1; --i) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; std::swap(leafOf[i - 1], leafOf[x % i]); }   // shuffled: leaf i sits in an arbitrary block
+	for (size_t i = 0; i < total; ++i) std::memcpy(leafOf[i], base.data() + (i % nbase) * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));
+	using clk = std::chrono::steady_clock;
+	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	size_t pos = 0;
+	while (pos < batches.size()) {
+		const size_t comma = batches.find(',', pos);
+		const size_t batch = std::stoul(batches.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos));
+		pos = comma == std::string::npos ? batches.size() : comma + 1;
+		auto backend = makeBackend(pack);
+		vqhip_codec* h = static_cast<HipBackend*>(backend.get())->handle();
+		auto check = [&](int rc) { if (rc != VQHIP_OK) throw std::runtime_error(vqhip_last_error(h)); };
+		double tPtr = 0, tCall = 0, tWrite = 0, first = 0;
+		size_t calls = 0;
+		std::vector<const float*> src(batch);
+		std::vector<uint8_t> idx(batch * 64);
+		std::vector<vqvdb::Coord3i> origins(batch);
+		const auto c0 = clk::now();
+		{
+			vqvdb::StreamWriter writer(tmp);
+			vqvdb::GridMeta meta;
+			meta.name = "density";
+			meta.latentShape = backend->getLatentShape();
+			meta.totalBlocks = total;
+			writer.startGrid(meta);
+			for (size_t start = 0; start < total; start += batch, ++calls) {
+				const size_t B = std::min(batch, total - start);
+				const auto t0 = clk::now();
+				for (size_t i = 0; i < B; ++i) origins[i] = originOf(start + i), src[i] = leafOf[start + i];
+				const auto t1 = clk::now();
+				check(vqhip_encode_leaves(h, src.data(), static_cast<int64_t>(B), idx.data()));
+				const auto t2 = clk::now();
+				writer.writeBatch(idx.data(), origins.data(), B);
+				const auto t3 = clk::now();
+				if (calls == 0) first = ms(t1, t2);
+				else tPtr += ms(t0, t1), tCall += ms(t1, t2), tWrite += ms(t2, t3);
+			}
+			writer.endGrid();
+			writer.close();
+		}
+		const double wallC = ms(c0, clk::now());
+		const double nc = calls > 1 ? double(calls - 1) : 1.0;
+		std::printf("loopbench-ptrs compress   batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: pointers %.4f ms, encode %.4f ms, frame+write %.4f ms\n",
+		            batch, total, wallC, total / wallC / 1e3, first, tPtr / nc, tCall / nc, tWrite / nc);
+		for (size_t i = 0; i < total; i += 4097) leafOf[i][0] = -1.0f;   // (decode must overwrite these)
+		double tRead = 0, tDec = 0;
+		first = 0, calls = 0;
+		size_t leafNo = 0;
+		std::vector<float*> dst(batch);
+		const auto d0 = clk::now();
+		{
+			vqvdb::StreamReader reader(tmp);
+			while (reader.hasNextGrid()) {
+				reader.nextGrid();
+				std::vector<uint8_t> ridx;
+				std::vector<vqvdb::Coord3i> rorg;
+				while (reader.hasNext()) {
+					const auto t0 = clk::now();
+					const size_t B = reader.nextBatch(batch, ridx, rorg);
+					if (B == 0) break;
+					for (size_t i = 0; i < B; ++i) dst[i] = leafOf[leafNo + i];   // stand-in for touchLeaf(origin)->buffer().data()
+					const auto t1 = clk::now();
+					check(vqhip_decode_leaves(h, ridx.data(), static_cast<int64_t>(B), dst.data()));
+					const auto t2 = clk::now();
+					if (calls == 0) first = ms(t1, t2);
+					else tRead += ms(t0, t1), tDec += ms(t1, t2);
+					leafNo += B;
+					++calls;
+				}
+			}
+		}
+		const double wallD = ms(d0, clk::now());
+		const double nd = calls > 1 ? double(calls - 1) : 1.0;
+		std::printf("loopbench-ptrs decompress batch %zu: %zu leaves in %.1f ms = %.4f M leaves/s | first call %.3f ms | per call: read+deframe+pointers %.4f ms, decode %.4f ms, leaf copies %.4f ms\n",
+		            batch, leafNo, wallD, leafNo / wallD / 1e3, first, tRead / nd, tDec / nd, 0.0);
+		if (leafNo != total) return 1;
+		for (size_t i = 0; i < total; i += 4097)
+			if (!(leafOf[i][0] > 0.0f && leafOf[i][0] < 1.0f)) { std::fprintf(stderr, "loopbench-ptrs: leaf %zu was not written\n", i); return 1; }
+		for (size_t i = 0; i < total; ++i) std::memcpy(leafOf[i], base.data() + (i % nbase) * LEAF_VOXELS, LEAF_VOXELS * sizeof(float));   // the next batch size compresses the same input
+	}
+	std::remove(tmp.c_str());
+	return 0;
+}
+
 int errors(const std::string& pack) {
 	int bad = 0;
 	auto expectThrow = [&](const char* what, auto&& fn, const char* msg) {
@@ -512,6 +613,67 @@ int errors(const std::string& pack) {
 	std::printf(bad ? "errors: %d failures\n" : "errors: all behaviours match (%d failures)\n", bad);
 	return bad ? 1 : 0;
 }
+
+// Two codecs, two caller threads — the SOP node caches own one codec each (SOP_VQVDB_Encoder.hpp:43-50) and Houdini may cook an encoder
+// node and a decoder node at the same time.  Thread A encodes on backend 1 while thread B decodes on backend 2 (mixed batch sizes), then
+// B creates / destroys backends while A keeps encoding; every result must equal the serial run's bytes.
+int threads(const std::string& pack, size_t iters) {
+	auto be1 = makeBackend(pack), be2 = makeBackend(pack);
+	const size_t sizes[] = {64, 1, 333, 1024, 4096, 20000, 97, 8192};
+	constexpr size_t NS = sizeof(sizes) / sizeof(sizes[0]), MAXB = 20000;
+	std::vector<float> leaves(MAXB * LEAF_VOXELS);
+	uint32_t st = 12345u;
+	for (auto& v : leaves) { st = st * 1664525u + 1013904223u; v = static_cast<float>(st >> 8) * (1.0f / 16777216.0f); }
+	auto view = [&](const void* p, size_t B, bool enc) {
+		TensorView v;
+		v.data = p;
+		v.shape = enc ? std::vector<int64_t>{static_cast<int64_t>(B), 1, 8, 8, 8} : std::vector<int64_t>{static_cast<int64_t>(B), 4, 4, 4};
+		v.dtype = enc ? DataType::FLOAT32 : DataType::UINT8;
+		return v;
+	};
+	// serial truth on a third backend
+	std::vector<std::vector<std::byte>> wantIdx(NS), wantRec(NS);
+	{
+		auto be0 = makeBackend(pack);
+		for (size_t k = 0; k < NS; ++k) {
+			const Tensor e = be0->encode(view(leaves.data(), sizes[k], true));
+			wantIdx[k] = e.buffer;
+			wantRec[k] = be0->decode(view(wantIdx[k].data(), sizes[k], false)).buffer;
+		}
+	}
+	std::atomic<int> bad{0};
+	std::atomic<bool> stop{false};
+	std::string firstError;
+	std::mutex emu;
+	auto guard = [&](auto&& fn) {
+		try { fn(); } catch (const std::exception& e) { std::lock_guard<std::mutex> lk(emu); if (firstError.empty()) firstError = e.what(); ++bad; }
+	};
+	{	// phase 1: encode on backend 1 || decode on backend 2
+		std::thread A([&] { guard([&] { for (size_t i = 0; i < iters; ++i) { const size_t k = i % NS; if (be1->encode(view(leaves.data(), sizes[k], true)).buffer != wantIdx[k]) ++bad; } }); });
+		std::thread B([&] { guard([&] { for (size_t i = 0; i < iters; ++i) { const size_t k = (i * 3 + 1) % NS; if (be2->decode(view(wantIdx[k].data(), sizes[k], false)).buffer != wantRec[k]) ++bad; } }); });
+		A.join();
+		B.join();
+	}
+	size_t churn = 0, encodes = 0;
+	{	// phase 2: create / destroy churn on B while A keeps encoding
+		std::thread A([&] { guard([&] { for (size_t i = 0; !stop.load(); ++i, ++encodes) { const size_t k = i % NS; if (be1->encode(view(leaves.data(), sizes[k], true)).buffer != wantIdx[k]) ++bad; } }); });
+		std::thread B([&] {
+			guard([&] {
+				for (size_t i = 0; i < std::max<size_t>(iters / 4, 8); ++i, ++churn) {
+					auto tmp = makeBackend(pack);
+					const size_t k = i % 3;
+					if (tmp->decode(view(wantIdx[k].data(), sizes[k], false)).buffer != wantRec[k]) ++bad;
+				}
+			});
+			stop = true;
+		});
+		A.join();
+		B.join();
+	}
+	std::printf("threads: %zu iterations encode || decode on two backends, %zu create/destroy cycles beside %zu encodes: %d mismatches%s%s\n", iters, churn, encodes,
+	            bad.load(), firstError.empty() ? "" : ", first exception: ", firstError.c_str());
+	return bad ? 1 : 0;
+}
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -522,12 +684,14 @@ int main(int argc, char** argv) {
 		if (mode == "compress_stream" && argc == 6) return compressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "decompress_stream" && argc == 6) return decompressStream(argv[2], argv[3], argv[4], std::stoul(argv[5]));
 		if (mode == "errors" && argc == 3) return errors(argv[2]);
+		if (mode == "threads" && argc == 4) return threads(argv[2], std::stoul(argv[3]));
 		if (mode == "loopbench" && argc == 6) return loopbench(argv[2], std::stoul(argv[3]), argv[4], argv[5], 1);
 		// ... with the pack loop and the leaf copies on N threads (0 = hardware_concurrency() / 2: what tbb::parallel_for uses in the reference)
 		if (mode == "loopbench" && argc == 7) {
 			const unsigned t = static_cast<unsigned>(std::stoul(argv[6]));
 			return loopbench(argv[2], std::stoul(argv[3]), argv[4], argv[5], t ? t : std::max(1u, std::thread::hardware_concurrency() / 2));
 		}
+		if (mode == "loopbench_ptrs" && argc == 6) return loopbenchPtrs(argv[2], std::stoul(argv[3]), argv[4], argv[5]);
 		if (mode == "streamtest" && argc == 3) return streamtest(argv[2]);
 		if (mode == "readcheck" && argc == 4) return readcheck(argv[2], std::stoul(argv[3]));
 		if (mode == "makefile" && argc == 4) return makefile(argv[2], std::stoul(argv[3]));

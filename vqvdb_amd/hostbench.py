@@ -57,7 +57,7 @@ def write_index_file(path: str, indices_fn, n: int, chunk: int = 1 << 20, name: 
             f.write(rec.tobytes())
 
 
-LOOP_RE = re.compile(r"loopbench(?:-mt)? (compress|decompress)\s+batch (\d+): (\d+) leaves in ([\d.]+) ms = ([\d.]+) M leaves/s \| first call ([\d.]+) ms \| "
+LOOP_RE = re.compile(r"loopbench(?:-mt|-ptrs)? (compress|decompress)\s+batch (\d+): (\d+) leaves in ([\d.]+) ms = ([\d.]+) M leaves/s \| first call ([\d.]+) ms \| "
                      r"per call: [\w+]+ ([\d.]+) ms, (?:encode|decode) ([\d.]+) ms, [\w+ ]+ ([\d.]+) ms")
 
 
@@ -72,8 +72,8 @@ def orchestrator_loop(harness: str, W: dict, tmpdir: str, n: int, batches=(64, 1
                        "(SOP_VQVDB_Encoder.cpp:33-38), and the backend's chunk 65536",
            "leaves": n, "batches": {}}
     try:
-        def one(extra, into):
-            r = subprocess.run([harness, "loopbench", pk, str(n), tmp, ",".join(str(b) for b in batches)] + extra, capture_output=True, text=True, timeout=900)
+        def one(extra, into, mode="loopbench"):
+            r = subprocess.run([harness, mode, pk, str(n), tmp, ",".join(str(b) for b in batches)] + extra, capture_output=True, text=True, timeout=900)
             if r.returncode != 0:
                 return {"error": (r.stderr or r.stdout)[-400:]}
             for m in LOOP_RE.finditer(r.stdout):
@@ -93,6 +93,14 @@ def orchestrator_loop(harness: str, W: dict, tmpdir: str, n: int, batches=(64, 1
         err = one([str(threads)], res["threaded"]["batches"])
         if err:
             res["threaded"] = err
+        # ... and the loops re-written on the leaf-pointer entry points: what the extension buys over the kept loop
+        res["leaf_pointers"] = {"note": "the same two loops on vqhip_encode_leaves / vqhip_decode_leaves: the caller hands over per-leaf pointers (one 2 KiB heap block per "
+                                        "leaf, shuffled, like OpenVDB leaf buffers); no pack buffer, no owning Tensor, no per-leaf copies on the caller's side — the library "
+                                        "gathers / scatters with its own threads through pinned staging, overlapped with the GPU; per_call.pack_ms = building the pointer array, "
+                                        "leaf_copy_ms = 0 by construction", "batches": {}}
+        err = one([], res["leaf_pointers"]["batches"], "loopbench_ptrs")
+        if err:
+            res["leaf_pointers"] = err
     finally:
         os.unlink(pk)
         if os.path.exists(tmp):
