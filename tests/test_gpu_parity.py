@@ -527,8 +527,9 @@ def test_large_path_kernel_variants_agree(pack, oracle, monkeypatch):
     leaves = np.concatenate([synth.make_leaves(2200, seed=31), synth.sparse_leaves(300, seed=32), synth.edge_leaves()])
     ref_idx = ref_rec = None
     for env in ({}, {"VQHIP_CONV8": "w8"}, {"VQHIP_CONV8": "rows"}, {"VQHIP_STEM": "split"}, {"VQHIP_STEM": "gather"}, {"VQHIP_FIRST": "steps"}, {"VQHIP_FIRST": "roll0"}, {"VQHIP_CONV4": "rows"},
-                {"VQHIP_DOWN": "rows"}, {"VQHIP_CONV4": "rows", "VQHIP_DOWN": "rows"}, {"VQHIP_TAIL": "slab"}, {"VQHIP_TAIL": "groups"}, {"VQHIP_TAIL": "rows32"}):
-        for k in ("VQHIP_CONV8", "VQHIP_STEM", "VQHIP_CONV4", "VQHIP_DOWN", "VQHIP_FIRST", "VQHIP_TAIL"):
+                {"VQHIP_DOWN": "rows"}, {"VQHIP_CONV4": "rows", "VQHIP_DOWN": "rows"}, {"VQHIP_TAIL": "slab"}, {"VQHIP_TAIL": "groups"}, {"VQHIP_TAIL": "rows32"},
+                {"VQHIP_FIRST_SRC": "raw"}, {"VQHIP_FIRST_SRC": "raw", "VQHIP_FIRST": "roll0"}):
+        for k in ("VQHIP_CONV8", "VQHIP_STEM", "VQHIP_CONV4", "VQHIP_DOWN", "VQHIP_FIRST", "VQHIP_TAIL", "VQHIP_FIRST_SRC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

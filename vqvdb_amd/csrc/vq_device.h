@@ -48,6 +48,11 @@ __device__ __forceinline__ vq_buf buf_of(const void* uniform_base)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_base, 0, 0x7fffffff, 0x00020000);
 }
+// ... with a range: loads beyond `bytes` return zeros (ragged last tile of a caller's buffer)
+__device__ __forceinline__ vq_buf buf_of_n(const void* uniform_base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_base, 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ f32x4 buf_ld16(vq_buf b, unsigned lane_bytes, unsigned uniform_bytes)
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)lane_bytes, (int)uniform_bytes, 0));

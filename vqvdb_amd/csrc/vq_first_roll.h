@@ -14,7 +14,7 @@
 #pragma once
 #include "vq_kernels.h"
 
-template <int MODE>
+template <int MODE, bool RAW = false>   // RAW: the caller's float[leaf][512] layout read directly (see conv_first_k)
 __global__ __launch_bounds__(256, 2) void conv_first_roll_k(ConvArgs A)
 {
     static_assert(MODE == 0 || MODE == 1, "statistics pass / normalising pass");
@@ -30,9 +30,17 @@ __global__ __launch_bounds__(256, 2) void conv_first_roll_k(ConvArgs A)
     const f32x4 bias4 = ((const f32x4*)A.bias_frag)[q4];
     // K slot q4 = kw (3 = pad): a lane's eight B operands of a row are the 8 floats from element kw of the row's record (0, x0..x7, 0);
     // the pad slot's lane offset lies beyond the descriptor's range and reads zeros (see conv_first_k)
-    const vq_buf xb = buf_of(A.in + (size_t)tile * VQ_XR_TILE);
-    const unsigned lane_x = q4 < 3 ? (unsigned)(jj * VQ_XR_REC + q4) * 4u : 0x80000000u;
-    auto ldrow = [&](int r, int hf) __attribute__((always_inline)) -> f32x4 { return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u); };
+    const vq_buf xb = RAW ? buf_of_n(A.in + (size_t)tile * 32 * 512, (unsigned)min((int64_t)32, A.n_leaves - (int64_t)tile * 32) * 2048u)
+                          : buf_of(A.in + (size_t)tile * VQ_XR_TILE);
+    const unsigned lane_x = q4 < 3 ? (RAW ? (unsigned)((sb * 16 + jj) * 512 + q4 - 1) * 4u : (unsigned)(jj * VQ_XR_REC + q4) * 4u) : 0x80000000u;   // (RAW: the leaf in the LANE offset, see conv_first_k)
+    const bool halo_lo = q4 == 0, halo_hi = q4 == 2;
+    auto ldrow = [&](int r, int hf) __attribute__((always_inline)) -> f32x4 {
+        if (!RAW) return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u);
+        f32x4 v = buf_ld16(xb, lane_x, (unsigned)(r * 8 + hf * 4) * 4u);
+        if (hf == 0) v.x = halo_lo ? 0.0f : v.x;
+        else v.w = halo_hi ? 0.0f : v.w;
+        return v;
+    };
     const bool has_out = A.out != nullptr;
     const vq_buf outb = buf_of(has_out ? (const f32x4*)A.out + (size_t)tile * 512 * 4 * 32 : (const f32x4*)A.in);
     const unsigned lane_o = (unsigned)(q4 * 32 + jj) * 16u;

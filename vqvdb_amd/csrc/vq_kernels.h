@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256) void pack_leaves_k(const float* __restrict__ l
 //   MODE 1: recompute y1, a1 = relu(gn(y1)) -> store, statistics of a1 for GroupNorm(8,16).
 // ------------------------------------------------------------------------------------------
 // ABL (tools/ablate/conv_first_ablate.hip only): 1 no input loads inside the loop, 2 no MFMAs, 4 no statistics, 8 no stores
-template <int MODE, int ABL = 0>
+// RAW (round 6): the loads read the CALLER'S layout float[leaf][512] directly instead of the row layout pack_leaves_k writes (one launch and
+// 5 KiB per leaf of traffic less): a lane's 8 floats of (row, kw) start at element row * 8 + kw - 1 of its leaf; the two halo elements that
+// fall into the neighbouring rows (x[-1] of the kw = 0 slot, x[8] of the kw = 2 slot) are replaced by zeros with a lane select, leaves past
+// n_leaves lie beyond the tile's buffer range and read as zeros.  Same operands, same MFMAs.  Measured SLOWER than the row layout + pack_leaves_k (a load touches 16 cache lines instead of 6): kept behind VQHIP_FIRST_SRC=raw.
+template <int MODE, int ABL = 0, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* __restrict__ steps)
 {
     static_assert(ABL == 0 || VQ_ABLATE, "ABL is a timing-only ablation switch (tools/ablate, -DVQ_ABLATE=1)");
@@ -159,9 +163,20 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
     // (stride 0), so it contributes fmaf(0, 0, acc) exactly like the contract says.
     // Buffer addressing (see buf_ld16): row r, sub-tile sb, half row hf of this lane's K slot.  The pad slot's lane offset lies beyond
     // the descriptor's range, and an out-of-range buffer load returns 0.
-    const vq_buf xb = buf_of(A.in + (size_t)tile * VQ_XR_TILE);
-    const unsigned lane_x = q4 < 3 ? (unsigned)(jj * VQ_XR_REC + q4) * 4u : 0x80000000u;
-    auto ldrow = [&](int r, int sb, int hf) -> f32x4 { return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u); };
+    const vq_buf xb = RAW ? buf_of_n(A.in + (size_t)tile * 32 * 512, (unsigned)min((int64_t)32, A.n_leaves - (int64_t)tile * 32) * 2048u)
+                          : buf_of(A.in + (size_t)tile * VQ_XR_TILE);
+    const unsigned lane_x = q4 < 3 ? (RAW ? (unsigned)(jj * 512 + q4 - 1) * 4u : (unsigned)(jj * VQ_XR_REC + q4) * 4u) : 0x80000000u;
+    // (RAW: the leaf sits in the LANE offset for both sub-tiles, so that the range check of the ragged last tile sees it whatever the
+    // hardware does with the scalar offset)
+    const unsigned lane_x1 = q4 < 3 ? lane_x + 16u * 2048u : 0x80000000u;
+    const bool halo_lo = q4 == 0, halo_hi = q4 == 2;
+    auto ldrow = [&](int r, int sb, int hf) -> f32x4 {
+        if (!RAW) return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u);
+        f32x4 v = buf_ld16(xb, sb ? lane_x1 : lane_x, (unsigned)(r * 8 + hf * 4) * 4u);
+        if (hf == 0) v.x = halo_lo ? 0.0f : v.x;
+        else v.w = halo_hi ? 0.0f : v.w;
+        return v;
+    };
     const bool has_out = A.out != nullptr;
     const vq_buf outb = buf_of(has_out ? (const f32x4*)A.out + (size_t)tile * 512 * 4 * 32 : (const f32x4*)A.in);
     const unsigned lane_o = (unsigned)(q4 * 32 + jj) * 16u;

@@ -181,6 +181,8 @@ struct vqhip_codec {
     bool tail_groups = false; // ... VQHIP_TAIL=groups: the output planes in three groups instead of five units, every input plane read 2.5x instead of 3.5x (tail_groups16_k, vq_tail_groups.h; measured equal in time, 33 spilled registers)
     bool tail_rows32 = false; // ... VQHIP_TAIL=rows32: a whole 32-leaf tile per wave, one wave per SIMD (tail_rows32_k; measured 4 % slower)
     bool tail_rows = true;   // folded decoder tail of full chunks: 16-voxel tiles, zeros skipped along D and H (tail_rows16_k, vq_tail_rows.h); VQHIP_TAIL=slab selects conv_mfma32_k<OUTMODE 2> (depth only)
+    int host_split = 8;      // host-memory calls of one chunk are cut into up to host_split pieces of >= host_split_min leaves (VQHIP_HOST_SPLIT=n[,min]; 1 = off)
+    int64_t host_split_min = 8192;
     int tail16_tiles = 48;   // small-batch folded tail on the 16x16x4 MFMA up to this many tiles (VQHIP_TAIL16_TILES; measured: 1024 leaves 90 -> 56 us, 2048 leaves 92 -> 103 us)
     bool r64s_resident = true;   // small-batch 64->64 convs: their quarter of the weights LDS-resident (VQHIP_R64S=stream: streamed)
     int vq_split = 2;        // position ranges per tile in the VQ search of full chunks (VQHIP_VQ_SPLIT)
@@ -188,6 +190,8 @@ struct vqhip_codec {
     bool convdown_lds = true;   // down conv of large passes: input planes streamed through LDS once, weights from L1 / L2 (vq_convdown_lds.h); VQHIP_DOWN=rows selects the row kernel (input re-fetched 3.06x)
     bool conv4_lds = true;   // 32-channel 4^3 convs of large passes: input planes in an LDS ring, weights straight from L1 / L2 (vq_conv4_lds.h); VQHIP_CONV4=rows selects the row kernel (weights LDS-resident, every input row re-fetched 6.25x)
     bool first_roll_stats = false;   // ... for the statistics pass too (VQHIP_FIRST=roll0; measured slower)
+    bool first_raw = false;  // VQHIP_FIRST_SRC=raw: the first conv reads the caller's float[leaf][512] layout itself and pack_leaves_k is not launched (round 6; measured SLOWER: 0.425 + 0.465 ms against 0.069 + 0.322 + 0.396 ms with the row layout — 16 cache lines per load instead of 6)
+    const float* cur_leaves = nullptr;   // the current pass's input leaves (device), for the split path's first conv
     bool first_roll = true;  // first conv of large passes, normalising pass: rolling row window in registers (vq_first_roll.h); VQHIP_FIRST=steps selects conv_first_k ((row, kd) steps, nine row loads per output row)
     bool conv8_lds = true;   // 16-channel 8^3 convs of large passes: LDS-plane kernel (vq_conv8_lds.h); VQHIP_CONV8=rows selects the row-group kernel
     int split_tiles = -1;    // position-split path: -1 = automatic (measured crossovers, use_split), >= 0 = plain tile threshold
@@ -1133,22 +1137,31 @@ int encode_chunk_split(vqhip_codec* c, Launcher& L, int64_t n, uint8_t* d_idx, h
         // mid-size batches: the first conv twice (statistics, then recompute + normalise + store), like the one-wave-per-tile path,
         // instead of storing its raw output and normalising it in an elementwise pass (2 x 32 KiB per leaf less traffic)
         ConvArgs A{};
-        A.in = a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        const bool raw = c->cur_leaves != nullptr;
+        A.in = raw ? c->cur_leaves : a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
         const int psf = split_factor(g4, 8, 16, 1024);
-        L.run("enc_conv_first_stats_s", [&] { hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        L.run("enc_conv_first_stats_s", [&] {
+            if (raw) hipLaunchKernelGGL((conv_first_k<0, 0, true>), dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+            else hipLaunchKernelGGL(conv_first_k<0>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+        });
         combine("enc_stats_y1", 4, 1.0 / 2048.0, S.y1m, S.y1r);
         A.out = a["e_a1"], A.in_mean = S.y1m, A.in_rstd = S.y1r, A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
         L.run("enc_conv_first_gn_s", [&] {   // (rolling row window: vq_first_roll.h)
-            if (c->first_roll) hipLaunchKernelGGL(conv_first_roll_k<1>, dim3((2 * nt + 3) / 4, psf), dim3(256), 0, s, A);
+            if (raw) hipLaunchKernelGGL((conv_first_roll_k<1, true>), dim3((2 * nt + 3) / 4, psf), dim3(256), 0, s, A);
+            else if (c->first_roll) hipLaunchKernelGGL(conv_first_roll_k<1>, dim3((2 * nt + 3) / 4, psf), dim3(256), 0, s, A);
             else hipLaunchKernelGGL(conv_first_k<1>, dim3(g4, psf), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
         });
         combine("enc_stats_a1", 8, 1.0 / 1024.0, S.a1m, S.a1r);
     } else {
         ConvArgs A{};
-        A.in = a["xr"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt;
+        const bool raw = c->cur_leaves != nullptr;
+        A.in = raw ? c->cur_leaves : a["xr"], A.out = a["e_y1"], A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"], A.n_tiles = nt, A.n_leaves = n;
         A.n_steps = c->nsteps["steps.rows8kd"], A.grp_start = od("steps.rows8kd"), A.part_s = ps, A.part_q = pq;
-        L.run("enc_conv_first_s", [&] { hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]); });
+        L.run("enc_conv_first_s", [&] {
+            if (raw) hipLaunchKernelGGL((conv_first_k<2, 0, true>), dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+            else hipLaunchKernelGGL(conv_first_k<2>, dim3(g4, split_factor(g4, 8, 16, 1024)), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+        });
         combine("enc_stats_y1", 4, 1.0 / 2048.0, S.y1m, S.y1r);
         ConvArgs B{};
         B.in = a["e_y1"], B.out = a["e_a1"], B.in_mean = S.y1m, B.in_rstd = S.y1r, B.in_gamma = w["eg0.w"], B.in_beta = w["eg0.b"];
@@ -1244,25 +1257,31 @@ int encode_chunk(vqhip_codec* c, const float* d_leaves, int64_t n, uint8_t* d_id
 
     // the position-major copy xt is only read by the training step (loss, first-conv weight gradients) and by debug fetches
     float* xt = (c->training || c->full_training || c->debug) ? a["xt"] : nullptr;
-    L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt, nt <= 128 ? 8 : 1), dim3(256), 0, s, d_leaves, a["xr"], xt, n); });
+    // raw: the first conv reads d_leaves itself; the row layout is still written when something else reads it (training, debug fetches, VQHIP_FIRST=steps' normalising pass)
+    const bool raw = c->first_raw && c->first_roll && !c->training && !c->full_training;
+    c->cur_leaves = raw ? d_leaves : nullptr;
+    if (!raw || xt) L.run("pack_leaves", [&] { hipLaunchKernelGGL(pack_leaves_k, dim3(nt, nt <= 128 ? 8 : 1), dim3(256), 0, s, d_leaves, a["xr"], xt, n); });
     if (use_split(c, nt, false)) return encode_chunk_split(c, L, n, d_idx, s, d_latent);
     {
         // first conv twice: statistics pass, then recompute + GroupNorm(4,16) + ReLU + statistics for res.gn1
         ConvArgs A{};
-        A.in = a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
-        A.out_mean = S.y1m, A.out_rstd = S.y1r, A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"];
+        A.in = raw ? d_leaves : a["xr"], A.out = (c->debug || c->keep_y1) ? a["e_y1"] : nullptr, A.wfrag = w["e0.w"], A.bias_frag = w["e0.b"];
+        A.out_mean = S.y1m, A.out_rstd = S.y1r, A.n_tiles = nt, A.n_steps = c->nsteps["steps.rows8kd"], A.n_leaves = n;
         // first_roll: a wave per 16-leaf sub-tile with a rolling 3 x 3 row window in registers (three row loads per output row instead of nine)
         const int gq = (2 * nt + 3) / 4;
         // (the normalising pass only: its stores compete with the loads — 0.458 -> 0.393 ms; the statistics pass runs 0.322 ms on the
         // (row, kd) kernel and 0.353 ms with the window, whose plane starts it cannot hide; VQHIP_FIRST=roll0 selects that as well)
         L.run("enc_conv_first_stats", [&] {
-            if (c->first_roll_stats) hipLaunchKernelGGL(conv_first_roll_k<0>, dim3(gq), dim3(256), 0, s, A);
+            if (raw && c->first_roll_stats) hipLaunchKernelGGL((conv_first_roll_k<0, true>), dim3(gq), dim3(256), 0, s, A);
+            else if (raw) hipLaunchKernelGGL((conv_first_k<0, 0, true>), dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
+            else if (c->first_roll_stats) hipLaunchKernelGGL(conv_first_roll_k<0>, dim3(gq), dim3(256), 0, s, A);
             else hipLaunchKernelGGL(conv_first_k<0>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
         });
         A.out = a["e_a1"], A.in_mean = S.y1m, A.in_rstd = S.y1r, A.in_gamma = w["eg0.w"], A.in_beta = w["eg0.b"];
         A.out_mean = S.a1m, A.out_rstd = S.a1r;
         L.run("enc_conv_first_gn", [&] {
-            if (c->first_roll) hipLaunchKernelGGL(conv_first_roll_k<1>, dim3(gq), dim3(256), 0, s, A);
+            if (raw) hipLaunchKernelGGL((conv_first_roll_k<1, true>), dim3(gq), dim3(256), 0, s, A);
+            else if (c->first_roll) hipLaunchKernelGGL(conv_first_roll_k<1>, dim3(gq), dim3(256), 0, s, A);
             else hipLaunchKernelGGL(conv_first_k<1>, dim3(g4), dim3(256), 0, s, A, (const int4*)w["steps.rows8kd"]);
         });
     }
@@ -1625,6 +1644,13 @@ int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool w
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->chunk_fitted) fit_chunk_to_free_memory(c), c->chunk_fitted = true;
     step = std::min(step > 0 ? std::min(step, c->chunk) : c->chunk, n);
+    // A call that fits ONE chunk but is large (a 65 536-leaf batch from the orchestrator loop or the leaf-pointer entry points) would run
+    // gather -> H2D -> kernels -> D2H -> scatter back to back (17.5 ms for 65 536 leaves against a 9.8 ms device pass): it is cut into
+    // host_split pieces so that the host phases of one piece overlap the device pass of its neighbours.  Results never depend on the cut.
+    if (n <= step && c->host_split > 1 && n >= 2 * c->host_split_min) {
+        const int64_t pieces = std::min<int64_t>(c->host_split, n / c->host_split_min);
+        step = ((n + pieces - 1) / pieces + 31) / 32 * 32;
+    }
     int rc = ensure_tables(c);
     if (!rc) rc = ensure_io(c, step);
     if (rc) return rc;
@@ -1823,9 +1849,14 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("VQHIP_DOWN")) c->convdown_lds = std::strcmp(e, "rows") != 0;
     if (const char* e = std::getenv("VQHIP_CONV4")) c->conv4_lds = std::strcmp(e, "rows") != 0;
+    if (const char* e = std::getenv("VQHIP_FIRST_SRC")) c->first_raw = std::strcmp(e, "raw") == 0;
     if (const char* e = std::getenv("VQHIP_FIRST")) c->first_roll = std::strcmp(e, "steps") != 0, c->first_roll_stats = std::strcmp(e, "roll0") == 0;
     if (const char* e = std::getenv("VQHIP_CONV8")) c->conv8_lds = std::strcmp(e, "rows") != 0, c->conv8_w16 = std::strcmp(e, "w8") != 0;
     if (const char* e = std::getenv("VQHIP_TAIL16_TILES")) c->tail16_tiles = std::atoi(e);
+    if (const char* e = std::getenv("VQHIP_HOST_SPLIT")) {
+        c->host_split = std::max(1, std::atoi(e));
+        if (const char* m = std::strchr(e, ',')) c->host_split_min = std::max(32, std::atoi(m + 1));
+    }
     if (const char* e = std::getenv("VQHIP_TAIL")) {
         if (std::strcmp(e, "rows16") && std::strcmp(e, "slab") && std::strcmp(e, "rows32") && std::strcmp(e, "groups") && *e) {
             c->err = std::string("VQHIP_TAIL=") + e + ": unknown folded-tail variant (rows16 | rows32 | groups | slab)";
