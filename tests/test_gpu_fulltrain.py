@@ -165,7 +165,7 @@ def test_groupnorm_backward_paths_agree(weights, monkeypatch):
     sums are added in another order, so every parameter gradient must agree to 2e-6 of its tensor's maximum (measured 2e-7 .. 5e-7; ragged tile, three tiles
     with a ragged last one, 1000 leaves); where the bias sums run changes no bit."""
     def grads(env, n):
-        for k in ("VQHIP_TRAIN_GNBWD", "VQHIP_TRAIN_BIAS"):
+        for k in ("VQHIP_TRAIN_GNBWD", "VQHIP_TRAIN_BIAS", "VQHIP_TRAIN_EMA_AT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -176,11 +176,13 @@ def test_groupnorm_backward_paths_agree(weights, monkeypatch):
         return g
     for n in (7, 65, 1000):
         fused, split, side = grads({}, n), grads({"VQHIP_TRAIN_GNBWD": "split"}, n), grads({"VQHIP_TRAIN_BIAS": "side"}, n)
+        main = grads({"VQHIP_TRAIN_BIAS": "main", "VQHIP_TRAIN_EMA_AT": "backward"}, n)   # round 5's arrangement: no reduction stream, statistics with the backward pass
         worst = max((float(np.abs(fused[k] - split[k]).max() / max(np.abs(split[k]).max(), 1e-30)), k) for k in fused)
         print(n, worst)
         assert worst[0] < 2e-6, (n, worst)
         for k in fused:
             assert np.array_equal(fused[k], side[k]), (n, k)
+            assert np.array_equal(fused[k], main[k]), (n, k)
 
 
 @pytest.mark.parametrize("folded", [True, False])

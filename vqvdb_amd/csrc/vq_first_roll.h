@@ -32,13 +32,15 @@ __global__ __launch_bounds__(256, 2) void conv_first_roll_k(ConvArgs A)
     // the pad slot's lane offset lies beyond the descriptor's range and reads zeros (see conv_first_k)
     const vq_buf xb = RAW ? buf_of_n(A.in + (size_t)tile * 32 * 512, (unsigned)min((int64_t)32, A.n_leaves - (int64_t)tile * 32) * 2048u)
                           : buf_of(A.in + (size_t)tile * VQ_XR_TILE);
-    const unsigned lane_x = q4 < 3 ? (RAW ? (unsigned)((sb * 16 + jj) * 512 + q4 - 1) * 4u : (unsigned)(jj * VQ_XR_REC + q4) * 4u) : 0x80000000u;   // (RAW: the leaf in the LANE offset, see conv_first_k)
+    const unsigned lane_x = q4 < 3 ? (RAW ? (unsigned)((sb * 16 + jj) * 512) * 4u : (unsigned)(jj * VQ_XR_REC + q4) * 4u) : 0x80000000u;   // (RAW: the leaf in the LANE offset, see conv_first_k)
     const bool halo_lo = q4 == 0, halo_hi = q4 == 2;
+    const unsigned raw_lo = lane_x + (q4 < 3 ? (unsigned)(q4 > 0 ? q4 - 1 : 0) * 4u : 0u);            // (no load starts outside its leaf: see conv_first_k)
+    const unsigned raw_hi = lane_x + (q4 < 3 ? (unsigned)(4 + (q4 == 2 ? 0 : q4 - 1)) * 4u : 0u);
     auto ldrow = [&](int r, int hf) __attribute__((always_inline)) -> f32x4 {
         if (!RAW) return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u);
-        f32x4 v = buf_ld16(xb, lane_x, (unsigned)(r * 8 + hf * 4) * 4u);
-        if (hf == 0) v.x = halo_lo ? 0.0f : v.x;
-        else v.w = halo_hi ? 0.0f : v.w;
+        f32x4 v = buf_ld16(xb, hf ? raw_hi : raw_lo, (unsigned)(r * 8) * 4u);
+        if (hf == 0) v = halo_lo ? (f32x4){0.0f, v.x, v.y, v.z} : v;
+        else v = halo_hi ? (f32x4){v.y, v.z, v.w, 0.0f} : v;
         return v;
     };
     const bool has_out = A.out != nullptr;

@@ -165,16 +165,18 @@ __global__ __launch_bounds__(256, 2) void conv_first_k(ConvArgs A, const int4* _
     // the descriptor's range, and an out-of-range buffer load returns 0.
     const vq_buf xb = RAW ? buf_of_n(A.in + (size_t)tile * 32 * 512, (unsigned)min((int64_t)32, A.n_leaves - (int64_t)tile * 32) * 2048u)
                           : buf_of(A.in + (size_t)tile * VQ_XR_TILE);
-    const unsigned lane_x = q4 < 3 ? (RAW ? (unsigned)(jj * 512 + q4 - 1) * 4u : (unsigned)(jj * VQ_XR_REC + q4) * 4u) : 0x80000000u;
-    // (RAW: the leaf sits in the LANE offset for both sub-tiles, so that the range check of the ragged last tile sees it whatever the
-    // hardware does with the scalar offset)
-    const unsigned lane_x1 = q4 < 3 ? lane_x + 16u * 2048u : 0x80000000u;
+    const unsigned lane_x = q4 < 3 ? (RAW ? (unsigned)(jj * 512) * 4u : (unsigned)(jj * VQ_XR_REC + q4) * 4u) : 0x80000000u;
+    // RAW: a load whose FIRST byte lies outside the buffer range is dropped whole, so no lane may start below its leaf or end above it:
+    // the kw = 0 slot starts at x[0] and shifts right by one (x[-1] = 0), the kw = 2 slot of the upper half starts at x[4] and shifts left
+    // (x[8] = 0).  The leaf sits in the LANE offset for both sub-tiles (the range check of the ragged last tile must see it).
     const bool halo_lo = q4 == 0, halo_hi = q4 == 2;
+    const unsigned raw_lo = lane_x + (q4 < 3 ? (unsigned)(q4 > 0 ? q4 - 1 : 0) * 4u : 0u);            // hf = 0: first element max(kw - 1, 0)
+    const unsigned raw_hi = lane_x + (q4 < 3 ? (unsigned)(4 + (q4 == 2 ? 0 : q4 - 1)) * 4u : 0u);     // hf = 1: first element 4 + kw - 1, kw = 2: 4
     auto ldrow = [&](int r, int sb, int hf) -> f32x4 {
         if (!RAW) return buf_ld16(xb, lane_x, (unsigned)((r * 32 + sb * 16) * VQ_XR_REC + hf * 4) * 4u);
-        f32x4 v = buf_ld16(xb, sb ? lane_x1 : lane_x, (unsigned)(r * 8 + hf * 4) * 4u);
-        if (hf == 0) v.x = halo_lo ? 0.0f : v.x;
-        else v.w = halo_hi ? 0.0f : v.w;
+        f32x4 v = buf_ld16(xb, (hf ? raw_hi : raw_lo) + (q4 < 3 && sb ? 16u * 2048u : 0u), (unsigned)(r * 8) * 4u);
+        if (hf == 0) v = halo_lo ? (f32x4){0.0f, v.x, v.y, v.z} : v;
+        else v = halo_hi ? (f32x4){v.y, v.z, v.w, 0.0f} : v;
         return v;
     };
     const bool has_out = A.out != nullptr;

@@ -246,9 +246,15 @@ struct vqhip_codec {
     size_t ft_part_bytes = 0;
     bool full_training = false, keep_y1 = false, weights_stale = false;
     bool train_gn_fused = true;      // GroupNorm + ReLU backward as one pass per layer (gn_bwd_fused_k); VQHIP_TRAIN_GNBWD=split: sums + finish + apply
-    bool train_bias_main = true;     // bias gradients on the data-gradient stream (VQHIP_TRAIN_BIAS=side: beside the weight gradients)
+    bool train_bias_main = true;     // bias gradients on the data-gradient stream when there is no reduction stream (VQHIP_TRAIN_BIAS=side: beside the weight gradients)
+    bool train_red_stream = true;    // round 6: bias sums, GroupNorm-affine / attention-weight reductions on a third stream (VQHIP_TRAIN_BIAS=main|side: the old arrangements)
+    bool train_ema_early = true;     // round 6: the codebook statistics start on the side stream as soon as the assignment exists, beside the decoder's forward (VQHIP_TRAIN_EMA_AT=backward: with the backward pass)
     bool train_side_stream = true;   // training backward: weight / bias gradients on a second stream beside the data-gradient chain (VQHIP_TRAIN_STREAMS=1: one stream)
     hipStream_t ft_side = nullptr;
+    hipStream_t ft_red_shared = nullptr;   // ... the same on a plain stream (shares a hardware queue with the weight-gradient stream): large batches
+    int64_t train_red_own_leaves = 2048;   // batches up to this size use ft_red (VQHIP_TRAIN_RED_OWN_LEAVES)
+    bool ft_egate_early = false;           // this step's encoder attention gates were computed beside the forward pass
+    hipStream_t ft_red = nullptr;    // third stream of the training step (round 6): the small reductions nothing on the data-gradient chain waits for (bias sums, GroupNorm-affine and attention-weight reductions)
     std::vector<hipEvent_t> ft_ev;   // fork / join events of the side stream, reused every step
     size_t ft_ev_next = 0;
     bool train_wgrad_rows = true;    // training backward: weight gradients of the k3 layers at 4^3 by wgrad_rows4_k (VQHIP_TRAIN_WGRAD=pairs: wgrad32_k)
@@ -1870,7 +1876,9 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD")) c->train_wgrad_rows = std::strcmp(e, "pairs") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_STREAMS")) c->train_side_stream = std::strcmp(e, "1") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_GNBWD")) c->train_gn_fused = std::strcmp(e, "split") != 0;
-    if (const char* e = std::getenv("VQHIP_TRAIN_BIAS")) c->train_bias_main = std::strcmp(e, "side") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_BIAS")) c->train_bias_main = std::strcmp(e, "side") != 0, c->train_red_stream = std::strcmp(e, "third") == 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_RED_OWN_LEAVES")) c->train_red_own_leaves = std::atoll(e);
+    if (const char* e = std::getenv("VQHIP_TRAIN_EMA_AT")) c->train_ema_early = std::strcmp(e, "backward") != 0;
     if (const char* e = std::getenv("VQHIP_STEM")) c->stem_fused = std::strcmp(e, "split") != 0, c->stem_taps = std::strcmp(e, "gather") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_TAIL")) c->train_folded_tail = std::strcmp(e, "unfolded") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_EMA")) c->train_ema_lists = std::strcmp(e, "scan") != 0;
@@ -1903,6 +1911,8 @@ void vqhip_destroy(vqhip_codec* c)
     if (c->ft_part) hipFree(c->ft_part);
     for (hipEvent_t e : c->ft_ev) hipEventDestroy(e);
     if (c->ft_side) hipStreamDestroy(c->ft_side);
+    if (c->ft_red) hipStreamDestroy(c->ft_red);
+    if (c->ft_red_shared) hipStreamDestroy(c->ft_red_shared);
     if (c->tr_recon) hipFree(c->tr_recon);
     if (c->tr_loss_part) hipFree(c->tr_loss_part);
     for (int i = 0; i < 2; ++i) {
