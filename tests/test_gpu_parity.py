@@ -394,6 +394,33 @@ def test_leaf_pointer_entry_points(pack):
     c.close()
 
 
+def test_large_one_chunk_host_calls_are_cut_into_pieces_without_changing_a_bit(pack, monkeypatch):
+    """Round 6: a host-memory call that fits one chunk but is large is cut into up to 8 pieces of >= 8192 leaves inside the library (gather,
+    H2D, kernels, D2H and scatter of neighbouring pieces overlap).  Block and leaf-pointer entry points, ragged sizes, pieces that are not a
+    multiple of a tile: identical bytes to the uncut call (VQHIP_HOST_SPLIT=1) and to a finer cut."""
+    n = 8 * 8192 - 37                                  # 7 pieces of 9357 -> rounded up to tiles, ragged last piece
+    base = synth.make_leaves(4096, seed=515)
+    leaves = np.tile(base, (-(-n // 4096), 1))[:n]
+    leaves[::7] *= 0.5                                 # (not all periods identical)
+    results = []
+    for env in ({"VQHIP_HOST_SPLIT": "1"}, {}, {"VQHIP_HOST_SPLIT": "5,4096"}):
+        monkeypatch.delenv("VQHIP_HOST_SPLIT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = HipCodec(pack)
+        idx = c.encode(leaves)
+        rec = c.decode(idx)
+        idx_p = c.encode_leaves([leaves[i] for i in range(n)])
+        out = np.zeros_like(leaves)
+        c.decode_leaves(idx, [out[i] for i in range(n)])
+        small = c.encode(leaves[:16383])               # below two pieces' worth: never cut
+        c.close()
+        assert np.array_equal(idx, idx_p) and np.array_equal(_bits(rec), _bits(out)) and np.array_equal(small, idx[:16383])
+        results.append((idx, rec))
+    for idx, rec in results[1:]:
+        assert np.array_equal(idx, results[0][0]) and np.array_equal(_bits(rec), _bits(results[0][1]))
+
+
 def test_in_process_multi_device_sharding(codec, pack):
     """vqhip_multi_*: leaf ranges over several device handles, one host thread each, results in place.
     Only one GPU is visible here, so the three 'devices' are three independent handles on device 0 —

@@ -24,7 +24,7 @@ def kernel_build_id():
 
 LAUNCH = [  # (regex on the kernel's demangled name, launch name used by the library's profiler)
     (r"conv_first_k<0[,>]", "enc_conv_first_stats"), (r"conv_first_k<1[,>]", "enc_conv_first_gn"),
-    (r"conv_first_roll_k<0>", "enc_conv_first_stats"), (r"conv_first_roll_k<1>", "enc_conv_first_gn"),   # round 4: rolling row window (normalising pass)
+    (r"conv_first_roll_k<0[,>]", "enc_conv_first_stats"), (r"conv_first_roll_k<1[,>]", "enc_conv_first_gn"),   # round 4: rolling row window (normalising pass)
     (r"conv8_c16_k<4, false, true, false>", "enc_res16_conv1"), (r"conv8_c16_k<4, true, false, false>", "enc_res16_conv2"),
     (r"conv8_lds_k<false, true", "enc_res16_conv1"), (r"conv8_lds_k<true, false", "enc_res16_conv2"),   # persistent grid = CUs: the large-batch launches
     (r"conv_rows16_k<16, 32, 8, 4, 4, 2, 1, 0, false, 8, false, true[,>]", "enc_down"),
