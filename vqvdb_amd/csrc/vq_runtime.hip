@@ -1654,7 +1654,7 @@ int run_pipeline(vqhip_codec* c, bool is_encode, int64_t n, int64_t step, bool w
     // A call that fits ONE chunk but is large (a 65 536-leaf batch from the orchestrator loop or the leaf-pointer entry points) would run
     // gather -> H2D -> kernels -> D2H -> scatter back to back (17.5 ms for 65 536 leaves against a 9.8 ms device pass): it is cut into
     // host_split pieces so that the host phases of one piece overlap the device pass of its neighbours.  Results never depend on the cut.
-    if (n <= step && c->host_split > 1 && n >= 2 * c->host_split_min) {
+    if (n <= step && c->host_split > 1 && n >= 2 * c->host_split_min && !c->debug) {   // (debug mode keeps a call's activations whole for vqhip_debug_fetch)
         const int64_t pieces = std::min<int64_t>(c->host_split, n / c->host_split_min);
         step = ((n + pieces - 1) / pieces + 31) / 32 * 32;
     }
