@@ -176,13 +176,15 @@ def test_groupnorm_backward_paths_agree(weights, monkeypatch):
         return g
     for n in (7, 65, 1000):
         fused, split, side = grads({}, n), grads({"VQHIP_TRAIN_GNBWD": "split"}, n), grads({"VQHIP_TRAIN_BIAS": "side"}, n)
-        main = grads({"VQHIP_TRAIN_BIAS": "main", "VQHIP_TRAIN_EMA_AT": "backward"}, n)   # round 5's arrangement: no reduction stream, statistics with the backward pass
+        main = grads({"VQHIP_TRAIN_BIAS": "main", "VQHIP_TRAIN_EMA_AT": "backward"}, n)   # round 5's arrangement: reductions between the chain's kernels, statistics with the backward pass
+        third = grads({"VQHIP_TRAIN_BIAS": "third"}, n)                                    # round 6, first form: the reductions on a third stream (default: two multi-job launches at the chain's end)
         worst = max((float(np.abs(fused[k] - split[k]).max() / max(np.abs(split[k]).max(), 1e-30)), k) for k in fused)
         print(n, worst)
         assert worst[0] < 2e-6, (n, worst)
         for k in fused:
             assert np.array_equal(fused[k], side[k]), (n, k)
             assert np.array_equal(fused[k], main[k]), (n, k)
+            assert np.array_equal(fused[k], third[k]), (n, k)
 
 
 @pytest.mark.parametrize("folded", [True, False])

@@ -345,6 +345,77 @@ __global__ __launch_bounds__(256) void chan_reduce_k(const float* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 6: the small reductions of a training step that nothing on the data-gradient chain waits for — per-channel sums of every
+// layer's dY (bias gradients), the channel reductions of the GroupNorm-affine partials, the attention-weight partials — as TWO launches
+// at the end of the chain instead of 40 between its kernels (vq_train_full.inc, Bwd::join).  A job list travels as a kernel argument;
+// a workgroup looks its job up by block index and runs exactly the arithmetic of csum_seq_k / chan_reduce_k / parts_reduce_k.
+// ------------------------------------------------------------------------------------------
+struct CsumJob {
+    const float* x;     // L4 [tile][NP][C/4][32][4]
+    float* part;        // [tile][C][32]
+    int C, NP, first_block;
+};
+constexpr int RED_MAX_CSUM = 16, RED_MAX_JOBS = 48;
+struct CsumJobs {
+    CsumJob j[RED_MAX_CSUM];
+    int n;
+};
+// grid = sum over the jobs of n_tiles * C / 16 workgroups of 128 threads (a tile's 64 C / 8 threads = C / 16 workgroups)
+__global__ __launch_bounds__(128) void csum_multi_k(CsumJobs J)
+{
+    int k = 0;
+    while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].first_block) ++k;   // (uniform)
+    const CsumJob job = J.j[k];
+    const int local = (int)blockIdx.x - job.first_block, upt = job.C / 16;
+    const int tile = local / upt, tid = (local % upt) * 128 + (int)threadIdx.x;
+    if (job.C == 64 && job.NP == 64) csum_seq_thread<64, 64>(job.x, job.part, tile, tid);
+    else if (job.C == 128 && job.NP == 64) csum_seq_thread<128, 64>(job.x, job.part, tile, tid);
+    else if (job.C == 32 && job.NP == 64) csum_seq_thread<32, 64>(job.x, job.part, tile, tid);
+    else if (job.C == 16 && job.NP == 512) csum_seq_thread<16, 512>(job.x, job.part, tile, tid);
+}
+struct RedJob {
+    const float* part;
+    float* dst;
+    int kind;           // 0: chan_reduce_k (part[tile][C][32], one workgroup per channel); 1: parts_reduce_k (part[p][n], 64 outputs per workgroup)
+    int n_parts, n, first_block;
+    float scale;
+};
+struct RedJobs {
+    RedJob j[RED_MAX_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void reduce_multi_k(RedJobs J)
+{
+    __shared__ float red[256];
+    int k = 0;
+    while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].first_block) ++k;   // (uniform)
+    const RedJob job = J.j[k];
+    const int b = (int)blockIdx.x - job.first_block, t = threadIdx.x;
+    if (job.kind == 0) {   // chan_reduce_k: thread t walks tiles t>>5, t>>5 + 8, ... for leaf t&31, then a fixed LDS tree
+        const int C = job.n, c = b;
+        float s = 0.0f;
+        for (int tile = t >> 5; tile < job.n_parts; tile += 8) s += job.part[((size_t)tile * C + c) * 32 + (t & 31)];
+        red[t] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (t < w) red[t] += red[t + w];
+            __syncthreads();
+        }
+        if (t == 0) job.dst[c] = job.scale * red[0];
+    } else {               // parts_reduce_k: wave w adds the parts w, w+4, ... ascending, the four wave sums in wave order
+        const int o = t & 63, w = t >> 6, i = b * 64 + o;
+        float s = 0.0f;
+        if (i < job.n) {
+#pragma unroll 4
+            for (int p = w; p < job.n_parts; p += 4) s += job.part[(size_t)p * job.n + i];
+        }
+        red[w * 64 + o] = s;
+        __syncthreads();
+        if (w == 0 && i < job.n) job.dst[i] = job.scale * (((red[o] + red[64 + o]) + red[128 + o]) + red[192 + o]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic weight gradient of a leaf-tile convolution: dW[co][ci][tap] = sum over leaves, valid (ip, po) pairs of the tap of
 // dY[po][co][leaf] * X'[ip][ci][leaf], X' = X, relu(GroupNorm(X)) or gate*X exactly as the forward kernel formed it on load.
 // The leaves are the MFMA K axis: the dY and X' blocks of one position pair are transposed through LDS ([channel][leaf], row

@@ -2055,13 +2055,12 @@ __device__ __forceinline__ void se_gates_block(int tile, int quad, int j, f32x4 
     }
 }
 
+// thread `tid` of the 64 C / 8 threads that own tile `tile`: lane = (leaf j, channel quad)
 template <int C, int NP>
-__global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict__ x, float* __restrict__ csum, const float* __restrict__ fc0 = nullptr,
-                                                         const float* __restrict__ fc2 = nullptr, float* __restrict__ gates = nullptr)
+__device__ __forceinline__ f32x4 csum_seq_thread(const float* __restrict__ x, float* __restrict__ csum, int tile, int tid)
 {
-    const int lane = threadIdx.x & 63, j = lane & 31;
-    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
-    const int tile = blockIdx.x;
+    const int lane = tid & 63, j = lane & 31;
+    const int quad = 2 * (tid >> 6) + (lane >> 5);
     const f32x4* in4 = (const f32x4*)x + (size_t)tile * NP * (C / 4) * 32 + quad * 32 + j;
     f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll(NP <= 64 ? 16 : 1)
@@ -2075,6 +2074,16 @@ __global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict
     csum[((size_t)tile * C + 4 * quad + 1) * 32 + j] = s.y;
     csum[((size_t)tile * C + 4 * quad + 2) * 32 + j] = s.z;
     csum[((size_t)tile * C + 4 * quad + 3) * 32 + j] = s.w;
+    return s;
+}
+template <int C, int NP>
+__global__ __launch_bounds__(64 * C / 8) void csum_seq_k(const float* __restrict__ x, float* __restrict__ csum, const float* __restrict__ fc0 = nullptr,
+                                                         const float* __restrict__ fc2 = nullptr, float* __restrict__ gates = nullptr)
+{
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int quad = 2 * (int)(threadIdx.x >> 6) + (lane >> 5);
+    const int tile = blockIdx.x;
+    const f32x4 s = csum_seq_thread<C, NP>(x, csum, tile, (int)threadIdx.x);
     if (gates) se_gates_block<C>(tile, quad, j, s, fc0, fc2, gates);   // (uniform)
 }
 

@@ -247,12 +247,14 @@ struct vqhip_codec {
     bool full_training = false, keep_y1 = false, weights_stale = false;
     bool train_gn_fused = true;      // GroupNorm + ReLU backward as one pass per layer (gn_bwd_fused_k); VQHIP_TRAIN_GNBWD=split: sums + finish + apply
     bool train_bias_main = true;     // bias gradients on the data-gradient stream when there is no reduction stream (VQHIP_TRAIN_BIAS=side: beside the weight gradients)
-    bool train_red_stream = true;    // round 6: bias sums, GroupNorm-affine / attention-weight reductions on a third stream (VQHIP_TRAIN_BIAS=main|side: the old arrangements)
+    bool train_red_stream = false;   // round 6, first attempt: bias sums, GroupNorm-affine / attention-weight reductions on a third stream (VQHIP_TRAIN_BIAS=third; fast or slow depending on the hardware queue the stream lands on)
+    bool train_red_deferred = true;  // round 6: ... as two multi-job launches at the end of the data-gradient chain (csum_multi_k, reduce_multi_k); VQHIP_TRAIN_BIAS=main|side|third: the other arrangements
     bool train_ema_early = true;     // round 6: the codebook statistics start on the side stream as soon as the assignment exists, beside the decoder's forward (VQHIP_TRAIN_EMA_AT=backward: with the backward pass)
     bool train_side_stream = true;   // training backward: weight / bias gradients on a second stream beside the data-gradient chain (VQHIP_TRAIN_STREAMS=1: one stream)
     hipStream_t ft_side = nullptr;
     hipStream_t ft_red_shared = nullptr;   // ... the same on a plain stream (shares a hardware queue with the weight-gradient stream): large batches
     int64_t train_red_own_leaves = 2048;   // batches up to this size use ft_red (VQHIP_TRAIN_RED_OWN_LEAVES)
+    bool train_r64_quarters = true;        // 64 -> 64 convs of small training batches in four cout quarters with resident weights (VQHIP_TRAIN_R64=whole: one workgroup per row)
     int train_wgrad_cu_pct = 100;          // wgrad_rows4_k: slices as a percentage of one-per-CU (VQHIP_TRAIN_WGRAD_CU_PCT)
     bool ft_egate_early = false;           // this step's encoder attention gates were computed beside the forward pass
     hipStream_t ft_red = nullptr;    // third stream of the training step (round 6): the small reductions nothing on the data-gradient chain waits for (bias sums, GroupNorm-affine and attention-weight reductions)
@@ -1877,7 +1879,9 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD")) c->train_wgrad_rows = std::strcmp(e, "pairs") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_STREAMS")) c->train_side_stream = std::strcmp(e, "1") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_GNBWD")) c->train_gn_fused = std::strcmp(e, "split") != 0;
-    if (const char* e = std::getenv("VQHIP_TRAIN_BIAS")) c->train_bias_main = std::strcmp(e, "side") != 0, c->train_red_stream = std::strcmp(e, "third") == 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_BIAS"))
+        c->train_bias_main = std::strcmp(e, "side") != 0, c->train_red_stream = std::strcmp(e, "third") == 0, c->train_red_deferred = std::strcmp(e, "deferred") == 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_R64")) c->train_r64_quarters = std::strcmp(e, "whole") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD_CU_PCT")) c->train_wgrad_cu_pct = std::min(100, std::max(10, std::atoi(e)));
     if (const char* e = std::getenv("VQHIP_TRAIN_RED_OWN_LEAVES")) c->train_red_own_leaves = std::atoll(e);
     if (const char* e = std::getenv("VQHIP_TRAIN_EMA_AT")) c->train_ema_early = std::strcmp(e, "backward") != 0;
