@@ -468,12 +468,11 @@ def main():
                                  "folded cost; forward + data gradients + weight gradients, TRAIN_ISSUED_FLOP in bench.py) over the measured time / 157.3 TFLOP/s: "
                                  "true utilisations, <= 1.  ratio_nominal_dense_* = 3 x the dense forward count of the reference ops over the same time: what the "
                                  "algebraic eliminations buy, not a utilisation (it exceeds 1 at 8192 leaves per rank)",
-                    "streams": 1 if os.environ.get("VQHIP_TRAIN_STREAMS") == "1" else 3,
-                    "streams_note": "three streams (round 6): the data-gradient chain on the caller's stream; weight gradients, the codebook statistics (started beside the "
-                                    "decoder's forward) and the tail fold on a second; bias sums and the GroupNorm-affine / attention-weight reductions on a third "
-                                    "(its own hardware queue up to 2048 leaves per rank, the second stream's queue above). by_class times are event spans on "
-                                    "any stream, they overlap, and summed_event_spans_ms_per_step exceeds ms_per_step; whole_step_frac (from the wall time) "
-                                    "is the utilisation of the step"}
+                    "streams": 1 if os.environ.get("VQHIP_TRAIN_STREAMS") == "1" else 2,
+                    "streams_note": "two streams: the data-gradient chain on the caller's stream, ending with the step's deferred reductions (bias sums, GroupNorm-affine "
+                                    "and attention-weight reductions as two multi-job launches, round 6); weight gradients, the codebook statistics (started beside the "
+                                    "decoder's forward) and the tail fold on the second. by_class times are event spans on either stream, they overlap, and "
+                                    "summed_event_spans_ms_per_step exceeds ms_per_step; whole_step_frac (from the wall time) is the utilisation of the step"}
             ksteps = max(2, min(args.steps, 6))
             for per_rank_b in (2048, 8192):
                 x = leaves[0][:per_rank_b]

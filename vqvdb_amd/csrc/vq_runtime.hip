@@ -255,6 +255,7 @@ struct vqhip_codec {
     hipStream_t ft_red_shared = nullptr;   // ... the same on a plain stream (shares a hardware queue with the weight-gradient stream): large batches
     int64_t train_red_own_leaves = 2048;   // batches up to this size use ft_red (VQHIP_TRAIN_RED_OWN_LEAVES)
     bool train_r64_quarters = true;        // 64 -> 64 convs of small training batches in four cout quarters with resident weights (VQHIP_TRAIN_R64=whole: one workgroup per row)
+    bool train_dgrad_small_lds = true;     // data gradients of the 4^3 layers with streamed weight windows (VQHIP_TRAIN_DGRAD=resident: LDS-resident weights)
     int train_wgrad_cu_pct = 100;          // wgrad_rows4_k: slices as a percentage of one-per-CU (VQHIP_TRAIN_WGRAD_CU_PCT)
     bool ft_egate_early = false;           // this step's encoder attention gates were computed beside the forward pass
     hipStream_t ft_red = nullptr;    // third stream of the training step (round 6): the small reductions nothing on the data-gradient chain waits for (bias sums, GroupNorm-affine and attention-weight reductions)
@@ -1882,6 +1883,7 @@ int vqhip_create(const char* pack_path, const void* pack_bytes, size_t pack_size
     if (const char* e = std::getenv("VQHIP_TRAIN_BIAS"))
         c->train_bias_main = std::strcmp(e, "side") != 0, c->train_red_stream = std::strcmp(e, "third") == 0, c->train_red_deferred = std::strcmp(e, "deferred") == 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_R64")) c->train_r64_quarters = std::strcmp(e, "whole") != 0;
+    if (const char* e = std::getenv("VQHIP_TRAIN_DGRAD")) c->train_dgrad_small_lds = std::strcmp(e, "resident") != 0;
     if (const char* e = std::getenv("VQHIP_TRAIN_WGRAD_CU_PCT")) c->train_wgrad_cu_pct = std::min(100, std::max(10, std::atoi(e)));
     if (const char* e = std::getenv("VQHIP_TRAIN_RED_OWN_LEAVES")) c->train_red_own_leaves = std::atoll(e);
     if (const char* e = std::getenv("VQHIP_TRAIN_EMA_AT")) c->train_ema_early = std::strcmp(e, "backward") != 0;
